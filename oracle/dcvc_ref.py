@@ -1,0 +1,532 @@
+"""ORACLE (test infrastructure only) -- CPU restatement of the DCVC-HEM per-frame path.
+
+This file is the checker, never the product: only tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg may import it.  It restates, in plain functional
+PyTorch-CPU fp32 over a ``{name: tensor}`` weight dict, what the reference computes in
+
+  /root/reference/DCVC_HEM/src/models/video_model.py   (DMC, P-frame codec)
+  /root/reference/DCVC_HEM/src/models/image_model.py   (IntraNoAR, I-frame codec)
+  /root/reference/DCVC_HEM/src/models/video_net.py     (SpyNet, warp, ResBlock, UNet ...)
+  /root/reference/DCVC_HEM/src/models/common_model.py  (dual prior, bit estimates)
+  /root/reference/DCVC_HEM/src/layers/layers.py        (residual blocks, sub-pixel convs)
+  /root/reference/DCVC_HEM/src/entropy_models/entropy_models.py (CDF tables, indexes)
+
+each function citing the lines it follows.  PINNING: tests/test_oracle_golden.py checks
+it against fixtures under tests/golden/ that tools/make_golden.py produced by importing
+the reference itself in the build container with the same name-seeded weights
+(vcm_ts_amd/params.py); see DESIGN.md "Oracle".
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+# ----------------------------------------------------------------------------- primitives
+
+
+def conv(w, name, x, stride=1):
+    wt = w[name + ".weight"]
+    return F.conv2d(x, wt, w[name + ".bias"], stride=stride, padding=wt.shape[-1] // 2)
+
+
+def lrelu(x, slope=0.01):
+    return F.leaky_relu(x, slope) if slope > 0 else F.relu(x)
+
+
+def subpel(w, name, x):
+    """conv followed by PixelShuffle(2) (layers.py:23-34)."""
+    return F.pixel_shuffle(conv(w, name + ".0", x), 2)
+
+
+def lower_bound(x, b):
+    """video_net.py:14-19 (forward value only)."""
+    return torch.clamp_min(x, b)
+
+
+def warp(feature, flow):
+    """video_net.py:32-50: grid_sample(bilinear, border, align_corners=True) on
+    linspace(-1,1) + flow / ((size-1)/2)."""
+    n, _, h, wd = flow.shape
+    gx = torch.linspace(-1.0, 1.0, wd).view(1, 1, 1, wd).expand(n, -1, h, -1)
+    gy = torch.linspace(-1.0, 1.0, h).view(1, 1, h, 1).expand(n, -1, -1, wd)
+    grid = torch.cat([gx, gy], 1) + torch.cat(
+        [flow[:, 0:1] / ((feature.size(3) - 1.0) / 2.0), flow[:, 1:2] / ((feature.size(2) - 1.0) / 2.0)], 1
+    )
+    return F.grid_sample(feature, grid.permute(0, 2, 3, 1), mode="bilinear", padding_mode="border", align_corners=True)
+
+
+def up2(x):
+    """video_net.py:58-63."""
+    return F.interpolate(x, (x.size(2) * 2, x.size(3) * 2), mode="bilinear", align_corners=False)
+
+
+def down2(x):
+    """video_net.py:66-71."""
+    return F.interpolate(x, (x.size(2) // 2, x.size(3) // 2), mode="bilinear", align_corners=False)
+
+
+# ----------------------------------------------------------------------------- blocks
+
+
+def res_block(w, name, x, slope=0.01, start_from_relu=True, end_with_relu=False):
+    """video_net.py:74-96 (bottleneck or not is implied by the weight shapes)."""
+    out = lrelu(x, slope) if start_from_relu else x
+    out = lrelu(conv(w, name + ".conv1", out), slope)
+    out = conv(w, name + ".conv2", out)
+    if end_with_relu:
+        out = lrelu(out, slope)
+    return x + out
+
+
+def residual_block(w, name, x):
+    """layers.py:104-127 (slope 0.01 on both activations)."""
+    out = lrelu(conv(w, name + ".conv1", x))
+    out = lrelu(conv(w, name + ".conv2", out))
+    return out + x
+
+
+def residual_block_stride(w, name, x):
+    """layers.py:42-73: conv s2 -> leaky(0.01) -> conv -> leaky(0.1), + 1x1 s2 skip."""
+    out = lrelu(conv(w, name + ".conv1", x, stride=2))
+    out = lrelu(conv(w, name + ".conv2", out), 0.1)
+    return out + conv(w, name + ".downsample", x, stride=2)
+
+
+def residual_block_up(w, name, x):
+    """layers.py:76-101."""
+    out = lrelu(subpel(w, name + ".subpel_conv", x))
+    out = lrelu(conv(w, name + ".conv", out), 0.1)
+    return out + subpel(w, name + ".upsample", x)
+
+
+def encoder_stack(w, name, x):
+    """video_net.py:227-235."""
+    for i in (0, 2, 4):
+        x = residual_block_stride(w, f"{name}.{i}", x)
+        x = residual_block(w, f"{name}.{i + 1}", x)
+    return conv(w, f"{name}.6", x, stride=2)
+
+
+def decoder_stack(w, name, x):
+    """video_net.py:237-246."""
+    for i in (0, 2, 4):
+        x = residual_block(w, f"{name}.{i}", x)
+        x = residual_block_up(w, f"{name}.{i + 1}", x)
+    x = residual_block(w, f"{name}.6", x)
+    return subpel(w, f"{name}.7", x)
+
+
+def hyper_enc5(w, name, x):
+    """video_net.py:252-262 (strides 1,1,2,1,2; LeakyReLU(0.01) between)."""
+    for i, s in ((0, 1), (2, 1), (4, 2), (6, 1)):
+        x = lrelu(conv(w, f"{name}.{i}", x, stride=s))
+    return conv(w, f"{name}.8", x, stride=2)
+
+
+def hyper_dec(w, name, x):
+    """video_net.py:264-274 / video_model.py:181-191."""
+    x = lrelu(conv(w, f"{name}.0", x))
+    x = lrelu(subpel(w, f"{name}.2", x))
+    x = lrelu(conv(w, f"{name}.4", x))
+    x = lrelu(subpel(w, f"{name}.6", x))
+    return conv(w, f"{name}.8", x)
+
+
+def three_convs(w, name, x, slope=0.2):
+    """the *_prior_fusion / *_spatial_prior stacks (video_model.py:150-164,199-213)."""
+    x = lrelu(conv(w, f"{name}.0", x), slope)
+    x = lrelu(conv(w, f"{name}.2", x), slope)
+    return conv(w, f"{name}.4", x)
+
+
+def se_conv_block(w, name, x):
+    """ConvBlockResidual with SELayer (video_net.py:149-179)."""
+    t = conv(w, f"{name}.conv.2", lrelu(conv(w, f"{name}.conv.0", x)))
+    s = t.mean(dim=(-1, -2))
+    s = torch.sigmoid(F.linear(F.relu(F.linear(s, w[f"{name}.conv.3.fc.0.weight"])), w[f"{name}.conv.3.fc.2.weight"]))
+    return conv(w, f"{name}.up_dim", x) + t * s[:, :, None, None]
+
+
+def unet(w, name, x):
+    """video_net.py:182-223."""
+    x1 = se_conv_block(w, f"{name}.conv1", x)
+    x2 = se_conv_block(w, f"{name}.conv2", F.max_pool2d(x1, 2))
+    x3 = se_conv_block(w, f"{name}.conv3", F.max_pool2d(x2, 2))
+    for i in range(4):
+        x3 = res_block(w, f"{name}.context_refine.{i}", x3, slope=0.0)
+    d3 = se_conv_block(w, f"{name}.up_conv3", torch.cat((x2, subpel(w, f"{name}.up3", x3)), 1))
+    return se_conv_block(w, f"{name}.up_conv2", torch.cat((x1, subpel(w, f"{name}.up2", d3)), 1))
+
+
+def spynet(w, im1, im2):
+    """ME_Spynet.forward + MEBasic (video_net.py:99-146)."""
+    p1, p2 = [im1], [im2]
+    for _ in range(3):
+        p1.append(F.avg_pool2d(p1[-1], 2, 2))
+        p2.append(F.avg_pool2d(p2[-1], 2, 2))
+    n, _, h, wd = p2[3].shape
+    flow = torch.zeros(n, 2, h // 2, wd // 2)
+    for lvl in range(4):
+        fu = up2(flow) * 2.0
+        k = 3 - lvl
+        x = torch.cat([p1[k], warp(p2[k], fu), fu], 1)
+        base = f"optic_flow.moduleBasic.{lvl}"
+        for i in (1, 2, 3, 4):
+            x = F.relu(conv(w, f"{base}.conv{i}", x))
+        flow = fu + conv(w, f"{base}.conv5", x)
+    return flow
+
+
+# ----------------------------------------------------------------------------- entropy model
+
+
+def checker_masks(h, wd):
+    """common_model.py:82-89: mask_0 = 1 where (row+col) even."""
+    yy, xx = torch.meshgrid(torch.arange(h), torch.arange(wd), indexing="ij")
+    m0 = ((yy + xx) % 2 == 0).float()[None, None]
+    return m0, 1.0 - m0
+
+
+def _masked(y, scales, means, mask):
+    """common_model.py:91-102 with eval-mode quant (round half to even)."""
+    sh, mh = scales * mask, means * mask
+    res = (y - mh) * mask
+    q = torch.round(res)
+    return res, q, q + mh, sh
+
+
+def dual_prior(w, prior_name, y, means, scales, qstep):
+    """forward_dual_prior (common_model.py:104-177), returning every tensor both the
+    estimate path and the write path need."""
+    _, _, h, wd = y.shape
+    m0, m1 = checker_masks(h, wd)
+    qstep = lower_bound(qstep, 0.5)
+    y = y / qstep
+    y0, y1 = y.chunk(2, 1)
+    s0, s1 = scales.chunk(2, 1)
+    u0, u1 = means.chunk(2, 1)
+    r00, q00, h00, sh00 = _masked(y0, s0, u0, m0)
+    r11, q11, h11, sh11 = _masked(y1, s1, u1, m1)
+    s0, u0, s1, u1 = three_convs(w, prior_name, torch.cat((h00, h11, means, scales, qstep), 1)).chunk(4, 1)
+    r01, q01, h01, sh01 = _masked(y0, s0, u0, m1)
+    r10, q10, h10, sh10 = _masked(y1, s1, u1, m0)
+    return {
+        "y_res": torch.cat((r00 + r01, r11 + r10), 1),
+        "y_q": torch.cat((q00 + q01, q11 + q10), 1),
+        "y_hat": torch.cat((h00 + h01, h11 + h10), 1) * qstep,
+        "scales_hat": torch.cat((sh00 + sh01, sh11 + sh10), 1),
+        "q_w0": q00 + q11,
+        "q_w1": q01 + q10,
+        "s_w0": sh00 + sh11,
+        "s_w1": sh01 + sh10,
+    }
+
+
+def probs_to_bits(p):
+    """common_model.py:51-55."""
+    return torch.clamp_min(-1.0 * torch.log(p + 1e-5) / math.log(2.0), 0)
+
+
+def laplace_bits(y, sigma):
+    """common_model.py:64-69."""
+    d = torch.distributions.laplace.Laplace(torch.zeros_like(sigma), sigma.clamp(1e-5, 1e10))
+    return probs_to_bits(d.cdf(y + 0.5) - d.cdf(y - 0.5))
+
+
+def gaussian_bits(y, sigma):
+    """common_model.py:57-62."""
+    d = torch.distributions.normal.Normal(torch.zeros_like(sigma), sigma.clamp(0.11, 1e10))
+    return probs_to_bits(d.cdf(y + 0.5) - d.cdf(y - 0.5))
+
+
+def factorized_cdf(w, name, x):
+    """BitEstimator.get_cdf / Bitparm.forward (entropy_models.py:68-73,109-117)."""
+    for i in (1, 2, 3):
+        x = x * F.softplus(w[f"{name}.f{i}.h"]) + w[f"{name}.f{i}.b"]
+        x = x + torch.tanh(x) * torch.tanh(w[f"{name}.f{i}.a"])
+    x = x * F.softplus(w[f"{name}.f4.h"]) + w[f"{name}.f4.b"]
+    return torch.sigmoid(x)
+
+
+def z_bits(w, name, z):
+    """common_model.py:71-73."""
+    return probs_to_bits(factorized_cdf(w, name, z + 0.5) - factorized_cdf(w, name, z - 0.5))
+
+
+SCALE_LEVELS = 256
+SCALE_MAX = 64.0
+
+
+def scale_indexes(scales, distribution="laplace"):
+    """GaussianEncoder.build_indexes (entropy_models.py:264-268)."""
+    smin = 0.01 if distribution == "laplace" else 0.11
+    step = (math.log(SCALE_MAX) - math.log(smin)) / (SCALE_LEVELS - 1)
+    s = torch.maximum(scales, torch.zeros_like(scales) + 1e-5)
+    return ((torch.log(s) - math.log(smin)) / step).clamp_(0, SCALE_LEVELS - 1).int()
+
+
+def pmf_to_quantized_cdf(pmf, precision=16):
+    """ops.cpp:24-82, restated with Python integers (float32 rounding as in the C++)."""
+    # static_cast<uint32_t>(std::round(p * 2^prec) + 0.5): float32 product (exact, power of
+    # two), round half away from zero, so floor(v + 0.5) for the non-negative v seen here
+    cdf = [0] + [int(math.floor(float(np.float32(p) * np.float32(1 << precision)) + 0.5)) for p in pmf]
+    total = sum(cdf) & 0xFFFFFFFF
+    cdf = [((1 << precision) * c) // total for c in cdf]
+    for i in range(1, len(cdf)):
+        cdf[i] += cdf[i - 1]
+    cdf[-1] = 1 << precision
+    for i in range(len(cdf) - 1):
+        if cdf[i] == cdf[i + 1]:
+            best_freq, best = 1 << 32, -1
+            for j in range(len(cdf) - 1):
+                fr = cdf[j + 1] - cdf[j]
+                if 1 < fr < best_freq:
+                    best_freq, best = fr, j
+            assert best != -1
+            if best < i:
+                for j in range(best + 1, i + 1):
+                    cdf[j] -= 1
+            else:
+                for j in range(i + 1, best + 1):
+                    cdf[j] += 1
+    return cdf
+
+
+def _rows_to_table(pmf, tail, lengths, max_len):
+    """EntropyCoder.pmf_to_cdf (entropy_models.py:24-32)."""
+    tab = torch.zeros((len(lengths), max_len + 2), dtype=torch.int32)
+    for i in range(len(lengths)):
+        row = torch.cat((pmf[i, : int(lengths[i])], tail[i]), 0).tolist()
+        c = pmf_to_quantized_cdf(row)
+        tab[i, : len(c)] = torch.tensor(c, dtype=torch.int32)
+    return tab
+
+
+def scale_table_cdfs(distribution="laplace"):
+    """GaussianEncoder.update (entropy_models.py:224-262) -> (cdf, lengths, offsets)."""
+    smin = 0.01 if distribution == "laplace" else 0.11
+    table = torch.exp(torch.linspace(math.log(smin), math.log(SCALE_MAX), SCALE_LEVELS))
+    Dist = torch.distributions.laplace.Laplace if distribution == "laplace" else torch.distributions.normal.Normal
+    center = torch.zeros_like(table) + 50
+    d = Dist(torch.zeros_like(table), table)
+    for i in range(50, 1, -1):
+        center = torch.where(d.cdf(torch.zeros_like(table) + i) > 0.9999, torch.zeros_like(table) + i, center)
+    center = center.int()
+    lengths = 2 * center + 1
+    max_len = int(lengths.max())
+    samples = (torch.arange(max_len) - center[:, None]).float()
+    sc = torch.zeros_like(samples) + table[:, None]
+    d = Dist(torch.zeros_like(sc), sc)
+    upper, lower = d.cdf(samples + 0.5), d.cdf(samples - 0.5)
+    tab = _rows_to_table(upper - lower, 2 * lower[:, :1], lengths, max_len)
+    return tab.numpy(), (lengths + 2).int().numpy(), (-center).int().numpy()
+
+
+def factorized_cdfs(w, name):
+    """BitEstimator.update (entropy_models.py:119-174) -> (cdf, lengths, offsets)."""
+    ch = w[f"{name}.f1.h"].shape[1]
+    med = torch.zeros(ch)
+
+    def cdf_at(v):  # v: (..., ch, ...) laid out as (1, ch, 1, K)
+        return factorized_cdf(w, name, v)
+
+    minima, maxima = med + 50, med + 50
+    for i in range(50, 1, -1):
+        p = cdf_at((torch.zeros_like(med) - i)[None, :, None, None]).squeeze()
+        minima = torch.where(p < 0.0001, torch.zeros_like(med) + i, minima)
+    for i in range(50, 1, -1):
+        p = cdf_at((torch.zeros_like(med) + i)[None, :, None, None]).squeeze()
+        maxima = torch.where(p > 0.9999, torch.zeros_like(med) + i, maxima)
+    minima, maxima = minima.int(), maxima.int()
+    start = med - minima
+    lengths = maxima + minima + 1
+    max_len = int(lengths.max())
+    samples = torch.arange(max_len)[None, :] + start[:, None, None]  # (ch, 1, K)
+    lower = cdf_at(samples - 0.5).squeeze(0)  # broadcasting as the reference: (ch, ch, K)
+    upper = cdf_at(samples + 0.5).squeeze(0)
+    pmf = (upper - lower)[:, 0, :]
+    tail = lower[:, 0, :1] + (1.0 - upper[:, 0, -1:])
+    tab = _rows_to_table(pmf, tail, lengths, max_len)
+    return tab.numpy(), (lengths + 2).int().numpy(), (-minima).int().numpy()
+
+
+# ----------------------------------------------------------------------------- P-frame codec
+
+
+def _q(w, basic, scale):
+    """get_curr_mv_y_q / get_curr_y_q (video_model.py:255-261)."""
+    return lower_bound(w[basic], 0.5) * scale
+
+
+def motion_compensation(w, dpb, mv):
+    """video_model.py:226-246."""
+    warpframe = warp(dpb["ref_frame"], mv)
+    mv2 = down2(mv) / 2
+    mv3 = down2(mv2) / 2
+    if dpb.get("ref_feature") is None:
+        f = conv(w, "feature_adaptor_I", dpb["ref_frame"])
+    else:
+        f = conv(w, "feature_adaptor_P", dpb["ref_feature"])
+    l1 = res_block(w, "feature_extractor.res_block1", conv(w, "feature_extractor.conv1", f))
+    l2 = res_block(w, "feature_extractor.res_block2", conv(w, "feature_extractor.conv2", l1, stride=2))
+    l3 = res_block(w, "feature_extractor.res_block3", conv(w, "feature_extractor.conv3", l2, stride=2))
+    c1, c2, c3 = warp(l1, mv), warp(l2, mv2), warp(l3, mv3)
+    n = "context_fusion_net"  # video_model.py:40-68
+    c3_up = res_block(w, f"{n}.res_block3_up", subpel(w, f"{n}.conv3_up", c3))
+    c3_out = res_block(w, f"{n}.res_block3_out", conv(w, f"{n}.conv3_out", c3))
+    cat2 = torch.cat((c3_up, c2), 1)
+    c2_up = res_block(w, f"{n}.res_block2_up", subpel(w, f"{n}.conv2_up", cat2))
+    c2_out = res_block(w, f"{n}.res_block2_out", conv(w, f"{n}.conv2_out", cat2))
+    c1_out = res_block(w, f"{n}.res_block1_out", conv(w, f"{n}.conv1_out", torch.cat((c2_up, c1), 1)))
+    return c1 + c1_out, c2 + c2_out, c3 + c3_out, warpframe
+
+
+def contextual_encoder(w, x, c1, c2, c3):
+    """video_model.py:71-90."""
+    n = "contextual_encoder"
+    f = conv(w, f"{n}.conv1", torch.cat([x, c1], 1), stride=2)
+    f = res_block(w, f"{n}.res1", torch.cat([f, c2], 1), slope=0.1, end_with_relu=True)
+    f = conv(w, f"{n}.conv2", f, stride=2)
+    f = res_block(w, f"{n}.res2", torch.cat([f, c3], 1), slope=0.1, end_with_relu=True)
+    return conv(w, f"{n}.conv4", conv(w, f"{n}.conv3", f, stride=2), stride=2)
+
+
+def contextual_decoder(w, y_hat, c2, c3):
+    """video_model.py:93-112."""
+    n = "contextual_decoder"
+    f = subpel(w, f"{n}.up2", subpel(w, f"{n}.up1", y_hat))
+    f = res_block(w, f"{n}.res1", torch.cat([f, c3], 1), slope=0.1, end_with_relu=True)
+    f = subpel(w, f"{n}.up3", f)
+    f = res_block(w, f"{n}.res2", torch.cat([f, c2], 1), slope=0.1, end_with_relu=True)
+    return subpel(w, f"{n}.up4", f)
+
+
+def recon_generation(w, recon_image_feature, context1):
+    """video_model.py:115-128, called as (recon_image_feature, context1) at :330/:412/:535:
+    the 32-channel decoder feature comes FIRST in the concatenation, then the 64-ch context."""
+    n = "recon_generation_net"
+    f = conv(w, f"{n}.first_conv", torch.cat((recon_image_feature, context1), 1))
+    f = unet(w, f"{n}.unet_2", unet(w, f"{n}.unet_1", f))
+    return f, conv(w, f"{n}.recon_conv", f)
+
+
+def dmc_analysis(w, x, dpb, mv_y_q_scale, y_q_scale):
+    """Everything forward_one_frame and compress share (video_model.py:263-330 /
+    470-535): all nets, eval-mode rounding.  Returns a dict of every intermediate the
+    callers below and the parity tests need."""
+    o = {}
+    q_mv = _q(w, "mv_y_q_basic", mv_y_q_scale)
+    q_y = _q(w, "y_q_basic", y_q_scale)
+    o["est_mv"] = spynet(w, x, dpb["ref_frame"])
+    mv_y = encoder_stack(w, "mv_encoder", o["est_mv"]) / q_mv
+    o["mv_z"] = hyper_enc5(w, "mv_hyper_prior_encoder", mv_y)
+    o["mv_z_hat"] = torch.round(o["mv_z"])
+    mv_params = hyper_dec(w, "mv_hyper_prior_decoder", o["mv_z_hat"])
+    ref_mv_y = dpb.get("ref_mv_y")
+    if ref_mv_y is None:
+        ref_mv_y = torch.zeros_like(mv_y)
+    qs, sc, mu = three_convs(w, "mv_y_prior_fusion", torch.cat((mv_params, ref_mv_y), 1)).chunk(3, 1)
+    o["mv"] = dual_prior(w, "mv_y_spatial_prior", mv_y, mu, sc, qs)
+    o["mv_y_hat"] = o["mv"]["y_hat"] * q_mv
+    o["mv_hat"] = decoder_stack(w, "mv_decoder", o["mv_y_hat"])
+    c1, c2, c3, o["warp_frame"] = motion_compensation(w, dpb, o["mv_hat"])
+    o["c1"], o["c2"], o["c3"] = c1, c2, c3
+    y = contextual_encoder(w, x, c1, c2, c3) / q_y
+    o["z"] = three_convs_hyper(w, y)
+    o["z_hat"] = torch.round(o["z"])
+    hier = hyper_dec(w, "contextual_hyper_prior_decoder", o["z_hat"])
+    temporal = conv(w, "temporal_prior_encoder.2", lrelu(conv(w, "temporal_prior_encoder.0", c3, stride=2), 0.1), stride=2)
+    ref_y = dpb.get("ref_y")
+    if ref_y is None:
+        ref_y = torch.zeros_like(y)
+    qs, sc, mu = three_convs(w, "y_prior_fusion", torch.cat((temporal, hier, ref_y), 1)).chunk(3, 1)
+    o["y"] = dual_prior(w, "y_spatial_prior", y, mu, sc, qs)
+    o["y_hat"] = o["y"]["y_hat"] * q_y
+    o["ctxdec"] = contextual_decoder(w, o["y_hat"], c2, c3)
+    o["feature"], o["recon"] = recon_generation(w, o["ctxdec"], c1)
+    return o
+
+
+def three_convs_hyper(w, y):
+    """contextual_hyper_prior_encoder (video_model.py:173-179): strides 1,2,2."""
+    n = "contextual_hyper_prior_encoder"
+    t = lrelu(conv(w, f"{n}.0", y))
+    t = lrelu(conv(w, f"{n}.2", t, stride=2))
+    return conv(w, f"{n}.4", t, stride=2)
+
+
+def dmc_forward_one_frame(w, x, dpb, mv_y_q_scale, y_q_scale):
+    """DMC.forward_one_frame in eval mode (video_model.py:470-592)."""
+    o = dmc_analysis(w, x, dpb, mv_y_q_scale, y_q_scale)
+    pix = x.size(2) * x.size(3)
+    s = lambda t: torch.sum(t, dim=(1, 2, 3)) / pix
+    r = {
+        "mse": s((x - o["recon"]) ** 2),
+        "me_mse": s((x - o["warp_frame"]) ** 2),
+        "bpp_y": s(laplace_bits(o["y"]["y_q"], o["y"]["scales_hat"])),
+        "bpp_mv_y": s(laplace_bits(o["mv"]["y_q"], o["mv"]["scales_hat"])),
+        "bpp_z": s(z_bits(w, "bit_estimator_z", o["z_hat"])),
+        "bpp_mv_z": s(z_bits(w, "bit_estimator_z_mv", o["mv_z_hat"])),
+    }
+    r["bpp"] = r["bpp_y"] + r["bpp_z"] + r["bpp_mv_y"] + r["bpp_mv_z"]
+    for k in ("", "_y", "_z", "_mv_y", "_mv_z"):
+        r["bit" + k] = torch.sum(r["bpp" + k]) * pix
+    r["dpb"] = {"ref_frame": o["recon"], "ref_feature": o["feature"], "ref_y": o["y_hat"], "ref_mv_y": o["mv_y_hat"]}
+    r["_inter"] = o
+    return r
+
+
+def dmc_symbol_planes(o):
+    """The six (symbols, scales-or-None) planes DMC.compress hands to the entropy coder,
+    in bitstream order (video_model.py:333-339)."""
+    return [
+        ("mv_z", o["mv_z_hat"], None),
+        ("mv_y0", o["mv"]["q_w0"], o["mv"]["s_w0"]),
+        ("mv_y1", o["mv"]["q_w1"], o["mv"]["s_w1"]),
+        ("z", o["z_hat"], None),
+        ("y0", o["y"]["q_w0"], o["y"]["s_w0"]),
+        ("y1", o["y"]["q_w1"], o["y"]["s_w1"]),
+    ]
+
+
+# ----------------------------------------------------------------------------- I-frame codec
+
+
+def intra_analysis(w, x, q_scale):
+    """IntraNoAR.forward / compress nets (image_model.py:54-75,148-165)."""
+    o = {}
+    q = lower_bound(w["q_basic"], 0.5) * q_scale
+    y = encoder_stack(w, "enc", x) / q
+    o["z"] = hyper_enc5(w, "hyper_enc", y)
+    o["z_hat"] = torch.round(o["z"])
+    qs, sc, mu = three_convs(w, "y_prior_fusion", hyper_dec(w, "hyper_dec", o["z_hat"])).chunk(3, 1)
+    o["y"] = dual_prior(w, "y_spatial_prior", y, mu, sc, qs)
+    o["y_hat"] = o["y"]["y_hat"] * q
+    o["x_hat"] = conv(w, "refine.1", unet(w, "refine.0", decoder_stack(w, "dec", o["y_hat"])))
+    return o
+
+
+def intra_forward(w, x, q_scale):
+    """IntraNoAR.forward in eval mode (image_model.py:54-106)."""
+    o = intra_analysis(w, x, q_scale)
+    pix = x.size(2) * x.size(3)
+    s = lambda t: torch.sum(t, dim=(1, 2, 3)) / pix
+    bpp_y = s(gaussian_bits(o["y"]["y_q"], o["y"]["scales_hat"]))
+    bpp_z = s(z_bits(w, "bit_estimator_z", o["z_hat"]))
+    return {
+        "x_hat": o["x_hat"],
+        "mse": s((x - o["x_hat"]) ** 2),
+        "bit": (torch.sum(bpp_y + bpp_z) * pix).item(),
+        "bpp": bpp_y + bpp_z,
+        "bpp_y": bpp_y,
+        "bpp_z": bpp_z,
+        "_inter": o,
+    }
+
+
+def intra_symbol_planes(o):
+    """image_model.py:168-171."""
+    return [("z", o["z_hat"], None), ("y0", o["y"]["q_w0"], o["y"]["s_w0"]), ("y1", o["y"]["q_w1"], o["y"]["s_w1"])]

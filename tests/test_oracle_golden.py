@@ -1,0 +1,107 @@
+"""Pins the CPU oracle (oracle/dcvc_ref.py) against fixtures produced by the REFERENCE
+itself (tools/make_golden.py imported /root/reference in the build container)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import dcvc_ref as R
+from tests.util import golden, oracle_weights, stats, crop
+from vcm_ts_amd.synthetic import frames
+
+# the oracle restates the same torch-CPU arithmetic, so it should agree to rounding noise
+RTOL = 2e-5
+
+
+def _run_sequence(name, h, w, n_p, seed, batch=1):
+    fx = golden(name)
+    wd, wi = oracle_weights("dmc"), oracle_weights("intra")
+    fr = frames(seed, n_p + 1, h, w)
+    if batch == 1:
+        xs = [torch.from_numpy(fr[t : t + 1]) for t in range(n_p + 1)]
+        iq = mvq = yq = 1.0
+    else:
+        fr2 = frames(seed + 100, n_p + 1, h, w)
+        xs = [torch.from_numpy(np.stack([fr[t], fr2[t]])) for t in range(n_p + 1)]
+        iq, mvq, yq = wi["q_scale"][:batch], wd["mv_y_q_scale"][:batch], wd["y_q_scale"][:batch]
+    with torch.no_grad():
+        ri = R.intra_forward(wi, xs[0], iq)
+        for k in ("mse", "bpp", "bpp_y", "bpp_z"):
+            np.testing.assert_allclose(ri[k].numpy(), fx[f"i_{k}"], rtol=RTOL)
+        np.testing.assert_allclose(crop(ri["x_hat"]), fx["i_xhat_crop"], rtol=1e-4, atol=1e-5)
+        if batch == 1:
+            o = ri["_inter"]
+            for tag, sym, sc in R.intra_symbol_planes(o):
+                np.testing.assert_array_equal(sym.numpy().astype(np.int16), fx[f"i_sym_{tag}"])
+                if sc is not None:
+                    np.testing.assert_array_equal(R.scale_indexes(sc, "gaussian").numpy().astype(np.int16), fx[f"i_idx_{tag}"])
+        dpb = {"ref_frame": ri["x_hat"], "ref_feature": None, "ref_y": None, "ref_mv_y": None}
+        for t in range(1, n_p + 1):
+            r = R.dmc_forward_one_frame(wd, xs[t], dpb, mvq, yq)
+            dpb = r["dpb"]
+            p = f"p{t}_"
+            for k in ("bpp_mv_y", "bpp_mv_z", "bpp_y", "bpp_z", "bpp", "me_mse", "mse"):
+                np.testing.assert_allclose(r[k].numpy(), fx[p + k], rtol=RTOL, err_msg=p + k)
+            for k in ("bit", "bit_y", "bit_z", "bit_mv_y", "bit_mv_z"):
+                np.testing.assert_allclose(r[k].item(), fx[p + k], rtol=RTOL)
+            for k, v in dpb.items():
+                np.testing.assert_allclose(stats(v)[:3], fx[p + k + "_stats"][:3], rtol=1e-4, err_msg=p + k)
+                np.testing.assert_allclose(crop(v), fx[p + k + "_crop"], rtol=1e-3, atol=1e-4)
+            o = r["_inter"]
+            np.testing.assert_allclose(stats(o["est_mv"])[:3], fx[p + "est_mv_stats"][:3], rtol=1e-4)
+            np.testing.assert_allclose(stats(o["mv_hat"])[:3], fx[p + "mv_hat_stats"][:3], rtol=1e-4)
+            for ci in (1, 2, 3):
+                np.testing.assert_allclose(stats(o[f"c{ci}"])[:3], fx[p + f"c{ci}_stats"][:3], rtol=1e-4)
+            if batch == 1:
+                for tag, sym, sc in R.dmc_symbol_planes(o):
+                    np.testing.assert_array_equal(sym.numpy().astype(np.int16), fx[p + f"sym_{tag}"], err_msg=tag)
+                    if sc is not None:
+                        np.testing.assert_array_equal(R.scale_indexes(sc).numpy().astype(np.int16), fx[p + f"idx_{tag}"])
+            if p + "recon_full" in fx:
+                np.testing.assert_allclose(dpb["ref_frame"].numpy(), fx[p + "recon_full"], rtol=1e-3, atol=1e-4)
+
+
+@pytest.mark.parametrize("name,h,w,n_p,seed", [("seq_64", 64, 64, 2, 0), ("seq_128", 128, 128, 2, 1), ("seq_192x320", 192, 320, 1, 3)])
+def test_sequence_matches_reference(name, h, w, n_p, seed):
+    _run_sequence(name, h, w, n_p, seed)
+
+
+def test_sequence_256(golden_dir):
+    _run_sequence("seq_256", 256, 256, 2, 2)
+
+
+def test_batch_of_rate_points():
+    _run_sequence("seq_64_b2", 64, 64, 2, 4, batch=2)
+
+
+def test_tables_match_reference():
+    fx = golden("tables")
+    for tag, dist in (("dmc", "laplace"), ("intra", "gaussian")):
+        c, l, o = R.scale_table_cdfs(dist)
+        np.testing.assert_array_equal(c, fx[f"{tag}_scale_cdf"])
+        np.testing.assert_array_equal(l, fx[f"{tag}_scale_len"])
+        np.testing.assert_array_equal(o, fx[f"{tag}_scale_off"])
+    for tag, kind, name in (("dmc_z", "dmc", "bit_estimator_z"), ("dmc_zmv", "dmc", "bit_estimator_z_mv"), ("intra_z", "intra", "bit_estimator_z")):
+        c, l, o = R.factorized_cdfs(oracle_weights(kind), name)
+        np.testing.assert_array_equal(c, fx[f"{tag}_cdf"])
+        np.testing.assert_array_equal(l, fx[f"{tag}_len"])
+        np.testing.assert_array_equal(o, fx[f"{tag}_off"])
+    s = torch.from_numpy(fx["idx_sweep_in"])
+    np.testing.assert_array_equal(R.scale_indexes(s.clone(), "laplace").numpy(), fx["idx_sweep_laplace"])
+    np.testing.assert_array_equal(R.scale_indexes(s.clone(), "gaussian").numpy(), fx["idx_sweep_gauss"])
+
+
+def test_pmf_to_quantized_cdf_matches_reference_build():
+    fx = golden("tables")
+    for k in range(int(fx["n_pmf"])):
+        got = R.pmf_to_quantized_cdf(fx[f"pmf_{k}"].tolist())
+        np.testing.assert_array_equal(np.array(got, np.int64), fx[f"qcdf_{k}"])
+
+
+def test_warp_and_resamplers_match_reference():
+    fx = golden("warp")
+    for k in range(int(fx["n_warp"])):
+        out = R.warp(torch.from_numpy(fx[f"warp{k}_im"]), torch.from_numpy(fx[f"warp{k}_flow"]))
+        np.testing.assert_allclose(out.numpy(), fx[f"warp{k}_out"], rtol=1e-6, atol=1e-6)
+    x = torch.from_numpy(fx["resamp_in"])
+    np.testing.assert_allclose(R.up2(x).numpy(), fx["resamp_up"], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(R.down2(x).numpy(), fx["resamp_down"], rtol=1e-6, atol=1e-7)

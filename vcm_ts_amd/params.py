@@ -1,0 +1,230 @@
+"""Parameter tables of the two codec networks and a name-seeded weight generator.
+
+The tables reproduce the *state-dict key names and shapes* of the reference's
+``DMC`` (406 tensors, /root/reference/DCVC_HEM/src/models/video_model.py:131-224)
+and ``IntraNoAR`` (175 tensors, image_model.py:16-48) so reference checkpoints
+load unchanged.  They are built from a compact description of the architecture
+(not from the reference's module classes): every entry is ``name -> shape``.
+
+``seeded_state_dict`` draws every tensor from a PRNG seeded by ``crc32(name)``,
+so the CPU oracle, the golden-fixture generator and the GPU box all regenerate
+bit-identical synthetic weights without shipping them.
+"""
+from __future__ import annotations
+
+import zlib
+from collections import OrderedDict
+
+import numpy as np
+
+Spec = "OrderedDict[str, tuple]"
+
+
+# ----------------------------------------------------------------------------- spec builders
+def _conv(t, name, cin, cout, k):
+    t[name + ".weight"] = (cout, cin, k, k)
+    t[name + ".bias"] = (cout,)
+
+
+def _bit_estimator(t, name, ch):
+    # four per-channel affine+tanh layers, the last without the tanh gate
+    # (entropy_models.py:54-100)
+    for i in (1, 2, 3, 4):
+        t[f"{name}.f{i}.h"] = (1, ch, 1, 1)
+        t[f"{name}.f{i}.b"] = (1, ch, 1, 1)
+        if i != 4:
+            t[f"{name}.f{i}.a"] = (1, ch, 1, 1)
+
+
+def _res_pair(t, name, cin, cmid, cout):
+    _conv(t, name + ".conv1", cin, cmid, 3)
+    _conv(t, name + ".conv2", cmid, cout, 3)
+
+
+def _enc_dec(t, enc, dec, cin, cout, ch):
+    # layers.py:42-127 + video_net.py:226-248
+    for i, c_in in ((0, cin), (2, ch), (4, ch)):
+        _res_pair(t, f"{enc}.{i}", c_in, ch, ch)
+        _conv(t, f"{enc}.{i}.downsample", c_in, ch, 1)
+        _res_pair(t, f"{enc}.{i + 1}", ch, ch, ch)
+    _conv(t, f"{enc}.6", ch, ch, 3)
+    for i in (0, 2, 4, 6):
+        _res_pair(t, f"{dec}.{i}", ch, ch, ch)
+        if i < 6:
+            _conv(t, f"{dec}.{i + 1}.subpel_conv.0", ch, ch * 4, 1)
+            _conv(t, f"{dec}.{i + 1}.conv", ch, ch, 3)
+            _conv(t, f"{dec}.{i + 1}.upsample.0", ch, ch * 4, 1)
+    _conv(t, f"{dec}.7.0", ch, cout * 4, 1)
+
+
+def _hyper_enc(t, name, y_ch, z_ch):
+    # video_net.py:251-262
+    _conv(t, f"{name}.0", y_ch, z_ch, 3)
+    for i in (2, 4, 6, 8):
+        _conv(t, f"{name}.{i}", z_ch, z_ch, 3)
+
+
+def _hyper_dec(t, name, y_ch, z_ch):
+    # video_net.py:264-274 (and the inline copy at video_model.py:181-191)
+    _conv(t, f"{name}.0", z_ch, y_ch, 3)
+    _conv(t, f"{name}.2.0", y_ch, y_ch * 4, 1)
+    _conv(t, f"{name}.4", y_ch, y_ch * 3 // 2, 3)
+    _conv(t, f"{name}.6.0", y_ch * 3 // 2, y_ch * 6, 1)
+    _conv(t, f"{name}.8", y_ch * 3 // 2, y_ch * 2, 3)
+
+
+def _three(t, name, c0, c1, c2, c3):
+    _conv(t, f"{name}.0", c0, c1, 3)
+    _conv(t, f"{name}.2", c1, c2, 3)
+    _conv(t, f"{name}.4", c2, c3, 3)
+
+
+def _se_block(t, name, cin, cout):
+    # ConvBlockResidual + SELayer (video_net.py:149-179)
+    _conv(t, f"{name}.conv.0", cin, cout, 3)
+    _conv(t, f"{name}.conv.2", cout, cout, 3)
+    t[f"{name}.conv.3.fc.0.weight"] = (cout // 16, cout)
+    t[f"{name}.conv.3.fc.2.weight"] = (cout, cout // 16)
+    _conv(t, f"{name}.up_dim", cin, cout, 1)
+
+
+def _unet(t, name, cin, cout):
+    # video_net.py:182-223
+    _se_block(t, f"{name}.conv1", cin, 32)
+    _se_block(t, f"{name}.conv2", 32, 64)
+    _se_block(t, f"{name}.conv3", 64, 128)
+    for i in range(4):
+        _res_pair(t, f"{name}.context_refine.{i}", 128, 128, 128)
+    _conv(t, f"{name}.up3.0", 128, 256, 1)
+    _se_block(t, f"{name}.up_conv3", 128, 64)
+    _conv(t, f"{name}.up2.0", 64, 128, 1)
+    _se_block(t, f"{name}.up_conv2", 64, cout)
+
+
+def dmc_spec(anchor_num: int = 4) -> Spec:
+    """name -> shape for the P-frame codec (video_model.py:131-224)."""
+    t = OrderedDict()
+    mv, n, m = 64, 64, 96
+    t["mv_y_q_basic"] = (1, mv, 1, 1)
+    t["mv_y_q_scale"] = (anchor_num, 1, 1, 1)
+    t["y_q_basic"] = (1, m, 1, 1)
+    t["y_q_scale"] = (anchor_num, 1, 1, 1)
+    _bit_estimator(t, "bit_estimator_z", 64)
+    _bit_estimator(t, "bit_estimator_z_mv", 64)
+    for lvl in range(4):  # SpyNet pyramid, video_net.py:99-122
+        for i, (ci, co) in enumerate(((8, 32), (32, 64), (64, 32), (32, 16), (16, 2)), 1):
+            _conv(t, f"optic_flow.moduleBasic.{lvl}.conv{i}", ci, co, 7)
+    _enc_dec(t, "mv_encoder", "mv_decoder", 2, 2, mv)
+    _hyper_enc(t, "mv_hyper_prior_encoder", mv, n)
+    _hyper_dec(t, "mv_hyper_prior_decoder", mv, n)
+    _three(t, "mv_y_prior_fusion", mv * 3, mv * 3, mv * 3, mv * 3)
+    _three(t, "mv_y_spatial_prior", mv * 4, mv * 3, mv * 3, mv * 2)
+    _conv(t, "feature_adaptor_I", 3, n, 3)
+    _conv(t, "feature_adaptor_P", n, n, 1)
+    for i in (1, 2, 3):
+        _conv(t, f"feature_extractor.conv{i}", n, n, 3)
+        _res_pair(t, f"feature_extractor.res_block{i}", n, n, n)
+    f = "context_fusion_net"
+    _conv(t, f"{f}.conv3_up.0", n, n * 4, 3)
+    _res_pair(t, f"{f}.res_block3_up", n, n, n)
+    _conv(t, f"{f}.conv3_out", n, n, 3)
+    _res_pair(t, f"{f}.res_block3_out", n, n, n)
+    _conv(t, f"{f}.conv2_up.0", n * 2, n * 4, 3)
+    _res_pair(t, f"{f}.res_block2_up", n, n, n)
+    _conv(t, f"{f}.conv2_out", n * 2, n, 3)
+    _res_pair(t, f"{f}.res_block2_out", n, n, n)
+    _conv(t, f"{f}.conv1_out", n * 2, n, 3)
+    _res_pair(t, f"{f}.res_block1_out", n, n, n)
+    e = "contextual_encoder"
+    _conv(t, f"{e}.conv1", n + 3, n, 3)
+    _res_pair(t, f"{e}.res1", 2 * n, n, 2 * n)
+    _conv(t, f"{e}.conv2", 2 * n, n, 3)
+    _res_pair(t, f"{e}.res2", 2 * n, n, 2 * n)
+    _conv(t, f"{e}.conv3", 2 * n, n, 3)
+    _conv(t, f"{e}.conv4", n, m, 3)
+    _three(t, "contextual_hyper_prior_encoder", m, n, n, n)
+    _hyper_dec(t, "contextual_hyper_prior_decoder", m, n)
+    _conv(t, "temporal_prior_encoder.0", n, m * 3 // 2, 3)
+    _conv(t, "temporal_prior_encoder.2", m * 3 // 2, m * 2, 3)
+    _three(t, "y_prior_fusion", m * 5, m * 4, m * 3, m * 3)
+    _three(t, "y_spatial_prior", m * 4, m * 3, m * 3, m * 2)
+    d = "contextual_decoder"
+    _conv(t, f"{d}.up1.0", m, n * 4, 3)
+    _conv(t, f"{d}.up2.0", n, n * 4, 3)
+    _res_pair(t, f"{d}.res1", 2 * n, n, 2 * n)
+    _conv(t, f"{d}.up3.0", 2 * n, n * 4, 3)
+    _res_pair(t, f"{d}.res2", 2 * n, n, 2 * n)
+    _conv(t, f"{d}.up4.0", 2 * n, 32 * 4, 3)
+    r = "recon_generation_net"
+    _conv(t, f"{r}.first_conv", n + 32, n, 3)
+    _unet(t, f"{r}.unet_1", n, n)
+    _unet(t, f"{r}.unet_2", n, n)
+    _conv(t, f"{r}.recon_conv", n, 3, 3)
+    return t
+
+
+def intra_spec(N: int = 192, anchor_num: int = 4) -> Spec:
+    """name -> shape for the I-frame codec (image_model.py:16-48)."""
+    t = OrderedDict()
+    t["q_basic"] = (1, N, 1, 1)
+    t["q_scale"] = (anchor_num, 1, 1, 1)
+    _bit_estimator(t, "bit_estimator_z", N)
+    _enc_dec(t, "enc", "dec", 3, 16, N)
+    _unet(t, "refine.0", 16, 16)
+    _conv(t, "refine.1", 16, 3, 3)
+    _hyper_enc(t, "hyper_enc", N, N)
+    _hyper_dec(t, "hyper_dec", N, N)
+    _three(t, "y_prior_fusion", N * 2, N * 3, N * 3, N * 3)
+    _three(t, "y_spatial_prior", N * 4, N * 3, N * 3, N * 2)
+    return t
+
+
+# ----------------------------------------------------------------------------- seeded weights
+# Measured on the reference itself (tools/make_golden.py --probe): gain 1.0 makes every
+# latent collapse to zero symbols, 1.4 overflows (mse ~ 1e3 and growing per frame); at 1.3
+# the latents stay |y| <~ 5 with bpp_y ~ 4-5 and the recursion is stable over a GOP.
+DEFAULT_GAIN = 1.3
+
+def _rng(name: str, seed: int) -> np.random.Generator:
+    return np.random.default_rng([zlib.crc32(name.encode()), seed])
+
+
+def seeded_tensor(name: str, shape: tuple, seed: int = 0, gain: float = DEFAULT_GAIN) -> np.ndarray:
+    """Deterministic synthetic value for one state-dict entry.
+
+    Conv/linear weights: N(0, s^2) with s = gain * sqrt(1 / fan_in) * 0.7 -- small enough
+    that activations stay O(1) through the ~60-conv-deep P-frame path (the
+    reference's own xavier(gain=sqrt 2) init, common_model.py:31-36, overflows
+    to mse ~ 1e10 and is useless for tolerance checks).  Biases: N(0, 0.02^2).
+    Quantisation-step parameters get spread-out positive values so all four rate
+    points differ; bit-estimator parameters follow the reference's N(0, 0.01^2)
+    init (entropy_models.py:58-64) widened so the 64 channels give different
+    tables.
+    """
+    g = _rng(name, seed)
+    leaf = name.rsplit(".", 1)[-1]
+    if name.endswith("q_basic"):
+        return (0.8 + 0.6 * g.random(shape)).astype(np.float32)
+    if name.endswith("q_scale"):
+        n = shape[0]
+        base = np.linspace(1.4, 0.6, n).reshape(shape)
+        return base.astype(np.float32)
+    if ".f1." in name or ".f2." in name or ".f3." in name or ".f4." in name:
+        if leaf == "h":
+            return (0.3 * g.standard_normal(shape) - 0.2).astype(np.float32)
+        return (0.1 * g.standard_normal(shape)).astype(np.float32)
+    if leaf == "bias":
+        return (0.02 * g.standard_normal(shape)).astype(np.float32)
+    # conv (cout, cin, k, k) or linear (out, in)
+    fan_in = int(np.prod(shape[1:]))
+    s = gain * 0.7 / np.sqrt(fan_in)
+    return (s * g.standard_normal(shape)).astype(np.float32)
+
+
+def seeded_state_dict(spec: Spec, seed: int = 0, gain: float = DEFAULT_GAIN):
+    """OrderedDict name -> torch.FloatTensor (CPU) for every entry of ``spec``."""
+    import torch
+
+    return OrderedDict(
+        (k, torch.from_numpy(seeded_tensor(k, shp, seed, gain))) for k, shp in spec.items()
+    )
