@@ -1,0 +1,181 @@
+/* dcvc_hip.h -- C ABI of the MI355X (gfx950) kernel layer for the DCVC-HEM per-frame path.
+ *
+ * Every entry point takes raw device pointers, plain sizes and a hipStream_t passed as
+ * void*; it returns 0 on success or a negative DCVC_E_* code (no exceptions, no torch
+ * types).  Work is enqueued on the given stream and is stream-ordered; buffers are owned by
+ * the caller.
+ *
+ * Activation layout in HBM: fp32 "NHWC with channel stride": element (n, y, x, c) of a
+ * tensor lives at  base[((n*H + y)*W + x)*cs + c],  cs >= C, cs % 4 == 0, base 16-byte
+ * aligned.  A channel slice of a wider buffer (zero-copy concatenation) is the same thing
+ * with base advanced by the channel offset.
+ *
+ * What each entry point replaces in the reference (file:line under /root/reference):
+ *   dcvc_conv2d             nn.Conv2d + bias + (Leaky)ReLU + residual add + nn.PixelShuffle(2)
+ *                           + torch.cat prologue: DCVC_HEM/src/layers/layers.py:18-127,
+ *                           src/models/video_net.py:74-115,165-223, video_model.py:17-128
+ *   dcvc_conv_pack_weights  (host) weight re-layout for dcvc_conv2d, run once per layer
+ *   dcvc_warp               flow_warp/torch_warp (F.grid_sample bilinear/border/align_corners)
+ *                           src/models/video_net.py:32-55
+ *   dcvc_up2_flow           bilinearupsacling(flow) * 2.0   video_net.py:58-63,139
+ *   dcvc_down2              bilineardownsacling(x) * scale  video_net.py:66-71, video_model.py:237-238
+ *                           and F.avg_pool2d(x, 2, 2)       video_net.py:132-133
+ *   dcvc_maxpool2           nn.MaxPool2d(2)                 video_net.py:185
+ *   dcvc_channel_mean, dcvc_se_gate   SELayer               video_net.py:149-162
+ *   dcvc_nchw_to_nhwc / dcvc_nhwc_to_nchw   boundary layout change (reference tensors are NCHW)
+ *   dcvc_scale_channels     y / curr_q, y_hat * curr_q      video_model.py:485,502,511,531
+ *   dcvc_round_symbols      torch.round(z) + .int()         video_model.py:284,310; entropy_models.py:185
+ *   dcvc_dual_prior_enc     CompressionModel.forward_dual_prior / process_with_mask / get_mask
+ *                           + GaussianEncoder.build_indexes src/models/common_model.py:82-177,
+ *                           src/entropy_models/entropy_models.py:264-268
+ *   dcvc_dual_prior_dec_*   CompressionModel.decompress_dual_prior  common_model.py:182-217
+ *   dcvc_laplace_bits / dcvc_gaussian_bits / dcvc_factorized_bits / dcvc_sq_err
+ *                           get_y_laplace_bits, get_y_gaussian_bits, get_z_bits, probs_to_bits,
+ *                           nn.MSELoss + per-sample sums    common_model.py:51-73, video_model.py:538-571
+ */
+#ifndef DCVC_HIP_H
+#define DCVC_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DCVC_OK 0
+#define DCVC_E_ARG (-1)      /* bad argument (shape, alignment, unsupported kernel size) */
+#define DCVC_E_LAUNCH (-2)   /* hipGetLastError() after the launch was not hipSuccess */
+
+#define DCVC_MAX_SEG 3
+
+/* One input segment of a convolution: the kernel walks segments in order, which is the
+ * channel order of the torch.cat the reference would have materialised. */
+typedef struct {
+    const float *ptr;   /* (N, H, W, cs) */
+    int32_t C;          /* channels used from this segment */
+    int32_t cs;         /* channel stride in floats */
+} dcvc_seg;
+
+typedef struct {
+    /* input */
+    dcvc_seg seg[DCVC_MAX_SEG];
+    int32_t nseg;
+    int32_t N, Hin, Win;
+    int32_t in_act;       /* 0: none, 1: LeakyReLU(in_slope) applied to the input on load */
+    float in_slope;
+    /* filter: packed by dcvc_conv_pack_weights */
+    const float *wpack;
+    const float *bpack;
+    int32_t ks;           /* 1, 3 or 7 (padding ks/2) */
+    int32_t stride;       /* 1 or 2 */
+    int32_t Cout;         /* real output channels (before pixel shuffle) */
+    int32_t Cout_pad;     /* as returned by dcvc_conv_pack_weights */
+    /* output */
+    float *out;           /* (N, Hout*ps, Wout*ps, out_cs) where ps = pixel_shuffle ? 2 : 1 */
+    int32_t out_cs;
+    int32_t out_act;      /* 0: none, 1: LeakyReLU(out_slope) after bias */
+    float out_slope;
+    int32_t pixel_shuffle;/* 1: write PixelShuffle(2) of the result (Cout % 4 == 0) */
+    const float *res;     /* optional residual added after the activation, laid out like out */
+    int32_t res_cs;
+    const float *res_gate;/* optional (N, Cfinal) per-sample per-channel factor on res (SE gate) */
+} dcvc_conv_args;
+
+/* Number of floats dcvc_conv_pack_weights writes to wpack for this geometry, and the padded
+ * output-channel count (bias length) through *cout_pad.  seg_C: channels per segment. */
+int64_t dcvc_conv_pack_size(int32_t Cout, int32_t ks, int32_t nseg, const int32_t *seg_C, int32_t *cout_pad);
+
+/* HOST function.  w: (Cout, sum(seg_C), ks, ks) fp32 as nn.Conv2d stores it; b: (Cout) or
+ * NULL.  Writes host buffers wpack / bpack which the caller uploads once. */
+int dcvc_conv_pack_weights(const float *w, const float *b, int32_t Cout, int32_t ks, int32_t nseg,
+                           const int32_t *seg_C, int32_t pixel_shuffle, float *wpack, float *bpack);
+
+int dcvc_conv2d(const dcvc_conv_args *a, void *stream);
+
+/* ---- resampling ------------------------------------------------------------------------ */
+/* out(n,y,x,c) = bilinear(src(n,.,.,c), x + flow(n,y,x,0), y + flow(n,y,x,1)), border clamp */
+int dcvc_warp(const float *src, int32_t src_cs, const float *flow, int32_t flow_cs, float *out, int32_t out_cs,
+              int32_t N, int32_t H, int32_t W, int32_t C, void *stream);
+/* x2 bilinear (align_corners=False) upsampling of a C-channel map times `scale`;
+ * out is (N, 2H, 2W, out_cs); out2 (optional) receives a second copy (out2_cs) */
+int dcvc_up2(const float *src, int32_t src_cs, float *out, int32_t out_cs, float *out2, int32_t out2_cs,
+             int32_t N, int32_t H, int32_t W, int32_t C, float scale, void *stream);
+/* 2x2 mean times `scale`; src is (N, H, W, .), H, W even.  avgpool_order = 0 sums in the order
+ * of F.interpolate(bilinear, x0.5), 1 in the order of F.avg_pool2d(2, 2) (same value up to 1 ulp) */
+int dcvc_down2(const float *src, int32_t src_cs, float *out, int32_t out_cs, int32_t N, int32_t H, int32_t W,
+               int32_t C, float scale, int32_t avgpool_order, void *stream);
+int dcvc_maxpool2(const float *src, int32_t src_cs, float *out, int32_t out_cs, int32_t N, int32_t H, int32_t W,
+                  int32_t C, void *stream);
+/* copy C channels between strided NHWC buffers */
+int dcvc_copy_channels(const float *src, int32_t src_cs, float *out, int32_t out_cs, int64_t npix, int32_t C,
+                       void *stream);
+int dcvc_nchw_to_nhwc(const float *src, float *out, int32_t out_cs, int32_t N, int32_t C, int32_t H, int32_t W,
+                      void *stream);
+int dcvc_nhwc_to_nchw(const float *src, int32_t src_cs, float *out, int32_t N, int32_t C, int32_t H, int32_t W,
+                      int32_t clamp01, void *stream);
+
+/* ---- squeeze-excitation ---------------------------------------------------------------- */
+/* mean(n, c) over H*W of a strided NHWC tensor, deterministic two-pass; scratch >= N*256*C floats */
+int dcvc_channel_mean(const float *src, int32_t src_cs, float *mean, float *scratch, int32_t N, int32_t HW,
+                      int32_t C, void *stream);
+/* gate = sigmoid(W2 relu(W1 mean)); W1: (Cr, C), W2: (C, Cr) as nn.Linear stores them */
+int dcvc_se_gate(const float *mean, const float *w1, const float *w2, float *gate, int32_t N, int32_t C,
+                 int32_t Cr, void *stream);
+
+/* ---- quantisation / entropy-model elementwise ------------------------------------------ */
+/* out = src / q  (mode 0) or src * q (mode 1);  q = max(q_basic[c], 0.5) * q_scale[n] */
+int dcvc_scale_channels(const float *src, int32_t src_cs, float *out, int32_t out_cs, const float *q_basic,
+                        const float *q_scale, int32_t mode, int32_t N, int32_t HW, int32_t C, void *stream);
+/* z_hat = rint(z) (half to even); sym (optional): int32 in (n, c, y, x) order */
+int dcvc_round_symbols(const float *z, int32_t z_cs, float *z_hat, int32_t zh_cs, int32_t *sym, int32_t N,
+                       int32_t H, int32_t W, int32_t C, void *stream);
+/* sym (n, c, y, x) int32 -> float NHWC */
+int dcvc_symbols_to_nhwc(const int32_t *sym, float *out, int32_t out_cs, int32_t N, int32_t H, int32_t W,
+                         int32_t C, void *stream);
+
+typedef struct {
+    const float *y;        /* (N,H,W,y_cs): latent already divided by curr_q (encoder only) */
+    int32_t y_cs;
+    const float *fusion;   /* (N,H,W,3C): [q_step | scales | means] from *_prior_fusion */
+    int32_t fusion_cs;
+    const float *spatial;  /* (N,H,W,2C): [scales_0 | means_0 | scales_1 | means_1]; step 2 only */
+    int32_t spatial_cs;
+    float *params;         /* (N,H,W,4C): [y_hat_0_0 | y_hat_1_1 | means | scales | q_step] */
+    int32_t params_cs;
+    float *y_hat;          /* (N,H,W,C) running y_hat in q_step units; step 2 finalises it */
+    float *y_q;            /* (N,H,W,C) rounded residual (estimate path) or NULL */
+    float *y_res;          /* (N,H,W,C) unrounded residual or NULL */
+    float *scales_hat;     /* (N,H,W,C) masked scales or NULL */
+    int32_t *sym;          /* (N, C/2, H, W) int32 symbols of this step or NULL */
+    int32_t *idx;          /* (N, C/2, H, W) int32 CDF indexes of this step or NULL */
+    float *out;            /* step 2: (N,H,W,out_cs) y_hat * q_step * curr_q */
+    int32_t out_cs;
+    const float *q_basic;  /* (C) */
+    const float *q_scale;  /* (N) */
+    int32_t N, H, W, C;
+    int32_t step;          /* 0 or 1 */
+    float log_scale_min;   /* ln(0.01) laplace / ln(0.11) gaussian */
+    float log_scale_step;  /* (ln 64 - log_scale_min) / 255 */
+} dcvc_dual_prior_args;
+
+int dcvc_dual_prior_enc(const dcvc_dual_prior_args *a, void *stream);
+/* decoder step: idx only (sym == NULL) or apply decoded symbols (sym != NULL) */
+int dcvc_dual_prior_dec_index(const dcvc_dual_prior_args *a, void *stream);
+int dcvc_dual_prior_dec_apply(const dcvc_dual_prior_args *a, void *stream);
+
+/* per-sample sums; out: (N) floats; scratch >= N*1024 floats.  kind: 0 laplace, 1 gaussian */
+int dcvc_scale_bits(const float *y_q, const float *scales_hat, float *out, float *scratch, int32_t kind, int32_t N,
+                    int64_t per_sample, void *stream);
+/* factorised prior bits of z_hat (N,H,W,C; cs): params (11, C): h1,b1,a1,h2,b2,a2,h3,b3,a3,h4,b4 */
+int dcvc_factorized_bits(const float *z_hat, int32_t z_cs, const float *params, float *out, float *scratch, int32_t N,
+                         int32_t HW, int32_t C, void *stream);
+/* sum over (y,x,c<C) of (a-b)^2 per sample */
+int dcvc_sq_err(const float *a, int32_t a_cs, const float *b, int32_t b_cs, float *out, float *scratch, int32_t N,
+                int32_t HW, int32_t C, void *stream);
+
+const char *dcvc_hip_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

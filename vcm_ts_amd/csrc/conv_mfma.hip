@@ -1,0 +1,297 @@
+// conv_mfma.hip -- implicit-GEMM 2-D convolution on the CDNA4 matrix cores, exact fp32.
+//
+// Replaces every nn.Conv2d of the reference's P-/I-frame networks together with the ops the
+// reference runs around it as separate kernels: torch.cat of the inputs (multi-segment
+// prologue), the (Leaky)ReLU before/after, the residual add, the SE gate and
+// nn.PixelShuffle(2) (permuting epilogue).  /root/reference/DCVC_HEM/src/layers/layers.py:18-127,
+// src/models/video_net.py:74-115,165-223, src/models/video_model.py:17-128.
+//
+// GEMM view:  Out[pixel][cout] = sum_{tap, cin} In[pixel + tap][cin] * W[tap][cin][cout]
+//   M = 32 consecutive output pixels of one row  (MFMA rows)
+//   N = 32 output channels                       (MFMA columns -> NHWC stores of 128 B)
+//   K = 16 input channels x KSxKS taps per chunk, fed two at a time to
+//       v_mfma_f32_32x32x2_f32 (f32 in / f32 accumulate: bitwise an fmaf chain, so the
+//       encoder and the decoder passes of the codec see identical numbers run to run).
+// A 256-thread workgroup (4 waves) owns a (4*RPW rows) x 32 px x (32*NT channels) output
+// tile; each wave keeps RPW x NT accumulators of 32x32.  Per 16-channel chunk the input
+// patch (with halo) and the filter slab are staged in LDS:
+//   patch [PH][PW][16 (+4 pad)] floats : row stride 20 dwords makes the per-lane
+//                                        ds_read_b128 of 4 channels conflict-free for
+//                                        stride-1 convs (bank start = 4*(5*lane mod 16))
+//   wl    [taps][4][32*NT][4]   floats : packed on the host so that the copy is linear and
+//                                        consecutive lanes read consecutive 16 B.
+// K order inside a chunk is permuted (lane-half h of the MFMA takes channels 8*k2+4*h+j):
+// A and B use the same permutation, so the sum is unchanged.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+#include <vector>
+
+#include "dcvc_hip.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int KC = 16;   // channels per K chunk
+constexpr int LDK = 20;  // padded channel stride of the LDS patch, in floats
+
+struct ConvK {
+    const float *seg_ptr[DCVC_MAX_SEG];
+    int seg_C[DCVC_MAX_SEG];
+    int seg_cs[DCVC_MAX_SEG];
+    int nseg;
+    int Hin, Win, Hout, Wout;
+    int in_act;
+    float in_slope;
+    const float *wpack;
+    const float *bpack;
+    int Cout, Cout_pad;
+    float *out;
+    int out_cs;
+    int out_act;
+    float out_slope;
+    int ps;
+    const float *res;
+    int res_cs;
+    const float *res_gate;
+};
+
+__device__ __forceinline__ float act(float v, float slope) { return v > 0.f ? v : v * slope; }
+
+template <int KS, int S, int RPW, int NT>
+__global__ __launch_bounds__(256, 2) void conv_mfma_f32(const ConvK a) {
+    constexpr int BH = 4 * RPW, BW = 32, BN = 32 * NT;
+    constexpr int PH = (BH - 1) * S + KS, PW = (BW - 1) * S + KS, PAD = KS / 2;
+    constexpr int T = KS * KS;
+    constexpr int TPS = (KS == 3 && S == 1) ? 9 : KS;  // taps staged in LDS at a time
+    constexpr int NST = T / TPS;
+    __shared__ __attribute__((aligned(16))) float lds[PH * PW * LDK + TPS * 4 * BN * 4];
+    float *patch = lds;
+    float *wl = lds + PH * PW * LDK;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nbn = a.Cout_pad / BN;
+    const int nb = blockIdx.x % nbn, tx = blockIdx.x / nbn;
+    const int x0 = tx * BW, y0 = blockIdx.y * BH, n0 = nb * BN, img = blockIdx.z;
+
+    f32x16 acc[RPW][NT];
+#pragma unroll
+    for (int m = 0; m < RPW; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+
+    const int a_base = ((wave * RPW * S) * PW + (lane & 31) * S) * LDK + (lane >> 5) * 4;
+    const int b_base = ((lane >> 5) * BN + (lane & 31)) * 4;
+
+    int cg = 0;
+    for (int s = 0; s < a.nseg; ++s) {
+        const int C = a.seg_C[s], cs = a.seg_cs[s];
+        const float *sp = a.seg_ptr[s] + (size_t)img * a.Hin * a.Win * cs;
+        for (int c0 = 0; c0 < C; c0 += KC, ++cg) {
+            __syncthreads();
+            for (int i = tid; i < PH * PW * 4; i += 256) {
+                const int p = i >> 2, q = i & 3;
+                const int py = p / PW, px = p - py * PW;
+                const int gy = y0 * S - PAD + py, gx = x0 * S - PAD + px;
+                const int c = c0 + q * 4;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (gy >= 0 && gy < a.Hin && gx >= 0 && gx < a.Win && c < C) {
+                    v = *(const f32x4 *)(sp + ((size_t)gy * a.Win + gx) * cs + c);
+                    if (c + 3 >= C) {
+                        if (c + 1 >= C) v[1] = 0.f;
+                        if (c + 2 >= C) v[2] = 0.f;
+                        v[3] = 0.f;
+                    }
+                    if (a.in_act) {
+                        v[0] = act(v[0], a.in_slope);
+                        v[1] = act(v[1], a.in_slope);
+                        v[2] = act(v[2], a.in_slope);
+                        v[3] = act(v[3], a.in_slope);
+                    }
+                }
+                *(f32x4 *)&patch[p * LDK + q * 4] = v;
+            }
+            for (int st = 0; st < NST; ++st) {
+                if (st > 0) __syncthreads();
+                const float *wsrc = a.wpack + ((size_t)(cg * T + st * TPS) * 4) * a.Cout_pad * 4 + (size_t)n0 * 4;
+                for (int i = tid; i < TPS * 4 * BN; i += 256) {
+                    const int row = i / BN, col = i - row * BN;
+                    *(f32x4 *)&wl[i * 4] = *(const f32x4 *)(wsrc + ((size_t)row * a.Cout_pad + col) * 4);
+                }
+                __syncthreads();
+                const int a_st = (TPS == T) ? 0 : st * PW * LDK;  // staged by filter row
+#pragma unroll
+                for (int tt = 0; tt < TPS; ++tt) {
+                    const int ky = (TPS == T) ? tt / KS : 0, kx = (TPS == T) ? tt % KS : tt;
+#pragma unroll
+                    for (int k2 = 0; k2 < 2; ++k2) {
+                        f32x4 af[RPW], bf[NT];
+#pragma unroll
+                        for (int m = 0; m < RPW; ++m)
+                            af[m] = *(const f32x4 *)&patch[a_base + a_st + ((m * S + ky) * PW + kx) * LDK + k2 * 8];
+#pragma unroll
+                        for (int n = 0; n < NT; ++n)
+                            bf[n] = *(const f32x4 *)&wl[b_base + ((tt * 4 + k2 * 2) * BN + n * 32) * 4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+#pragma unroll
+                            for (int m = 0; m < RPW; ++m)
+#pragma unroll
+                                for (int n = 0; n < NT; ++n)
+                                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[m][j], bf[n][j], acc[m][n], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+
+    // ---- epilogue: bias, activation, (gated) residual, NHWC or pixel-shuffled store
+    const int col = lane & 31, hh = lane >> 5;
+    const int Cq = a.Cout >> 2;
+    const int Cfin = a.ps ? Cq : a.Cout;
+    const int Ho = a.ps ? a.Hout * 2 : a.Hout, Wo = a.ps ? a.Wout * 2 : a.Wout;
+#pragma unroll
+    for (int m = 0; m < RPW; ++m) {
+        const int oy = y0 + wave * RPW + m;
+        if (oy >= a.Hout) continue;
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            const int ch = n0 + n * 32 + col;
+            if (ch >= a.Cout) continue;
+            const float bias = a.bpack[ch];
+            int dy = 0, dx = 0, cf = ch;
+            if (a.ps) {
+                const int sub = ch / Cq;
+                cf = ch - sub * Cq;
+                dy = sub >> 1;
+                dx = sub & 1;
+            }
+            const float gate = a.res_gate ? a.res_gate[(size_t)img * Cfin + cf] : 1.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ox = x0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                if (ox >= a.Wout) continue;
+                float v = acc[m][n][r] + bias;
+                if (a.out_act) v = act(v, a.out_slope);
+                const size_t pix = a.ps ? ((size_t)(img * Ho + 2 * oy + dy) * Wo + 2 * ox + dx)
+                                        : ((size_t)(img * Ho + oy) * Wo + ox);
+                if (a.res) {
+                    float rv = a.res[pix * a.res_cs + cf];
+                    if (a.res_gate) rv *= gate;
+                    v += rv;
+                }
+                a.out[pix * a.out_cs + cf] = v;
+            }
+        }
+    }
+}
+
+template <int KS, int S, int RPW, int NT>
+int launch(const ConvK &k, int N, hipStream_t st) {
+    constexpr int BH = 4 * RPW, BN = 32 * NT;
+    dim3 grid((unsigned)(((k.Wout + 31) / 32) * (k.Cout_pad / BN)), (unsigned)((k.Hout + BH - 1) / BH), (unsigned)N);
+    hipLaunchKernelGGL((conv_mfma_f32<KS, S, RPW, NT>), grid, dim3(256), 0, st, k);
+    return hipGetLastError() == hipSuccess ? DCVC_OK : DCVC_E_LAUNCH;
+}
+
+inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+}  // namespace
+
+extern "C" int64_t dcvc_conv_pack_size(int32_t Cout, int32_t ks, int32_t nseg, const int32_t *seg_C, int32_t *cout_pad) {
+    if (Cout <= 0 || nseg <= 0 || nseg > DCVC_MAX_SEG || (ks != 1 && ks != 3 && ks != 7)) return DCVC_E_ARG;
+    int chunks = 0;
+    for (int s = 0; s < nseg; ++s) chunks += (seg_C[s] + KC - 1) / KC;
+    const int cp = round_up(Cout, 32);
+    if (cout_pad) *cout_pad = cp;
+    return (int64_t)chunks * ks * ks * 4 * cp * 4;
+}
+
+// wpack[((chunk*T + tap)*4 + kq)*Cout_pad + n'][j] = w[n][cin(chunk, kq, j)][tap]
+// with n' = n, or for pixel shuffle n' = (n % 4) * (Cout/4) + n / 4 so that the four
+// sub-pixel planes are contiguous channel ranges.
+extern "C" int dcvc_conv_pack_weights(const float *w, const float *b, int32_t Cout, int32_t ks, int32_t nseg,
+                                      const int32_t *seg_C, int32_t pixel_shuffle, float *wpack, float *bpack) {
+    int32_t cp = 0;
+    const int64_t total = dcvc_conv_pack_size(Cout, ks, nseg, seg_C, &cp);
+    if (total < 0 || (pixel_shuffle && (Cout & 3))) return DCVC_E_ARG;
+    const int T = ks * ks;
+    int Cin = 0;
+    for (int s = 0; s < nseg; ++s) Cin += seg_C[s];
+    memset(wpack, 0, (size_t)total * sizeof(float));
+    memset(bpack, 0, (size_t)cp * sizeof(float));
+    const int Cq = Cout / 4;
+    int cg = 0, cin0 = 0;
+    for (int s = 0; s < nseg; ++s) {
+        for (int c0 = 0; c0 < seg_C[s]; c0 += KC, ++cg) {
+            for (int t = 0; t < T; ++t)
+                for (int kq = 0; kq < 4; ++kq)
+                    for (int j = 0; j < 4; ++j) {
+                        const int c = c0 + kq * 4 + j;
+                        if (c >= seg_C[s]) continue;
+                        for (int n = 0; n < Cout; ++n) {
+                            const int np = pixel_shuffle ? (n & 3) * Cq + (n >> 2) : n;
+                            wpack[((((size_t)cg * T + t) * 4 + kq) * cp + np) * 4 + j] =
+                                w[((size_t)n * Cin + cin0 + c) * T + t];
+                        }
+                    }
+        }
+        cin0 += seg_C[s];
+    }
+    for (int n = 0; n < Cout; ++n) {
+        const int np = pixel_shuffle ? (n & 3) * Cq + (n >> 2) : n;
+        bpack[np] = b ? b[n] : 0.f;
+    }
+    return DCVC_OK;
+}
+
+extern "C" int dcvc_conv2d(const dcvc_conv_args *a, void *stream) {
+    if (!a || a->nseg < 1 || a->nseg > DCVC_MAX_SEG || !a->out || !a->wpack || !a->bpack) return DCVC_E_ARG;
+    if (a->stride != 1 && a->stride != 2) return DCVC_E_ARG;
+    if (a->Cout_pad % 32 || a->Cout > a->Cout_pad || (a->pixel_shuffle && (a->Cout & 3))) return DCVC_E_ARG;
+    ConvK k;
+    memset(&k, 0, sizeof(k));
+    for (int s = 0; s < a->nseg; ++s) {
+        if (!a->seg[s].ptr || (a->seg[s].cs & 3) || a->seg[s].cs < round_up(a->seg[s].C, 4) ||
+            ((uintptr_t)a->seg[s].ptr & 15))
+            return DCVC_E_ARG;
+        k.seg_ptr[s] = a->seg[s].ptr;
+        k.seg_C[s] = a->seg[s].C;
+        k.seg_cs[s] = a->seg[s].cs;
+    }
+    k.nseg = a->nseg;
+    k.Hin = a->Hin;
+    k.Win = a->Win;
+    const int pad = a->ks / 2;
+    k.Hout = (a->Hin + 2 * pad - a->ks) / a->stride + 1;
+    k.Wout = (a->Win + 2 * pad - a->ks) / a->stride + 1;
+    k.in_act = a->in_act;
+    k.in_slope = a->in_slope;
+    k.wpack = a->wpack;
+    k.bpack = a->bpack;
+    k.Cout = a->Cout;
+    k.Cout_pad = a->Cout_pad;
+    k.out = a->out;
+    k.out_cs = a->out_cs;
+    k.out_act = a->out_act;
+    k.out_slope = a->out_slope;
+    k.ps = a->pixel_shuffle;
+    k.res = a->res;
+    k.res_cs = a->res_cs;
+    k.res_gate = a->res_gate;
+    hipStream_t st = (hipStream_t)stream;
+    const bool wide = (a->Cout_pad % 64) == 0;
+    const int key = a->ks * 10 + a->stride;
+    switch (key) {
+        case 11: return wide ? launch<1, 1, 2, 2>(k, a->N, st) : launch<1, 1, 2, 1>(k, a->N, st);
+        case 12: return wide ? launch<1, 2, 1, 2>(k, a->N, st) : launch<1, 2, 1, 1>(k, a->N, st);
+        case 31: return wide ? launch<3, 1, 2, 2>(k, a->N, st) : launch<3, 1, 2, 1>(k, a->N, st);
+        case 32: return wide ? launch<3, 2, 1, 2>(k, a->N, st) : launch<3, 2, 1, 1>(k, a->N, st);
+        case 71: return wide ? launch<7, 1, 2, 2>(k, a->N, st) : launch<7, 1, 2, 1>(k, a->N, st);
+        default: return DCVC_E_ARG;
+    }
+}

@@ -1,0 +1,140 @@
+"""ctypes bindings of the two C-ABI libraries (include/dcvc_hip.h, include/dcvc_rans.h).
+
+There is no fallback: if a library is missing the import of the product path fails loudly
+(`LibraryMissing`) -- build with ``python -c "import __graft_entry__ as g; g.build()"`` or
+``make -C vcm_ts_amd/csrc``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+
+
+class LibraryMissing(RuntimeError):
+    pass
+
+
+class KernelError(RuntimeError):
+    pass
+
+
+def _load(name):
+    path = os.path.join(CSRC, name)
+    if not os.path.exists(path):
+        raise LibraryMissing(f"{path} not built; run `make -C {CSRC}` (no CPU fallback exists)")
+    return C.CDLL(path)
+
+
+# ----------------------------------------------------------------------------- rans (host)
+_rans = None
+
+c_i32p = C.POINTER(C.c_int32)
+c_u8p = C.POINTER(C.c_uint8)
+c_f32p = C.POINTER(C.c_float)
+
+
+def rans():
+    global _rans
+    if _rans is None:
+        L = _load("libdcvc_rans.so")
+        L.dcvc_rans_encoder_create.restype = C.c_void_p
+        L.dcvc_rans_encoder_destroy.argtypes = [C.c_void_p]
+        L.dcvc_rans_encoder_reset.argtypes = [C.c_void_p]
+        L.dcvc_rans_encoder_encode_with_indexes.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
+                                                            C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
+        L.dcvc_rans_encoder_flush_bound.argtypes = [C.c_void_p]
+        L.dcvc_rans_encoder_flush_bound.restype = C.c_int64
+        L.dcvc_rans_encoder_flush.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+        L.dcvc_rans_encoder_flush.restype = C.c_int64
+        L.dcvc_rans_decoder_create.restype = C.c_void_p
+        L.dcvc_rans_decoder_destroy.argtypes = [C.c_void_p]
+        L.dcvc_rans_decoder_set_stream.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
+        L.dcvc_rans_decoder_decode_stream.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32,
+                                                      C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.dcvc_pmf_to_quantized_cdf.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
+        _rans = L
+    return _rans
+
+
+# ----------------------------------------------------------------------------- hip kernels
+class Seg(C.Structure):
+    _fields_ = [("ptr", C.c_void_p), ("C", C.c_int32), ("cs", C.c_int32)]
+
+
+class ConvArgs(C.Structure):
+    _fields_ = [
+        ("seg", Seg * 3), ("nseg", C.c_int32), ("N", C.c_int32), ("Hin", C.c_int32), ("Win", C.c_int32),
+        ("in_act", C.c_int32), ("in_slope", C.c_float), ("wpack", C.c_void_p), ("bpack", C.c_void_p),
+        ("ks", C.c_int32), ("stride", C.c_int32), ("Cout", C.c_int32), ("Cout_pad", C.c_int32),
+        ("out", C.c_void_p), ("out_cs", C.c_int32), ("out_act", C.c_int32), ("out_slope", C.c_float),
+        ("pixel_shuffle", C.c_int32), ("res", C.c_void_p), ("res_cs", C.c_int32), ("res_gate", C.c_void_p),
+    ]
+
+
+class DualPriorArgs(C.Structure):
+    _fields_ = [
+        ("y", C.c_void_p), ("y_cs", C.c_int32), ("fusion", C.c_void_p), ("fusion_cs", C.c_int32),
+        ("spatial", C.c_void_p), ("spatial_cs", C.c_int32), ("params", C.c_void_p), ("params_cs", C.c_int32),
+        ("y_hat", C.c_void_p), ("y_q", C.c_void_p), ("y_res", C.c_void_p), ("scales_hat", C.c_void_p),
+        ("sym", C.c_void_p), ("idx", C.c_void_p), ("out", C.c_void_p), ("out_cs", C.c_int32),
+        ("q_basic", C.c_void_p), ("q_scale", C.c_void_p), ("N", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
+        ("C", C.c_int32), ("step", C.c_int32), ("log_scale_min", C.c_float), ("log_scale_step", C.c_float),
+    ]
+
+
+_hip = None
+i32, i64, f32, vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
+
+_SIGS = {
+    "dcvc_conv2d": [C.POINTER(ConvArgs), vp],
+    "dcvc_conv_pack_weights": [vp, vp, i32, i32, i32, vp, i32, vp, vp],
+    "dcvc_warp": [vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, vp],
+    "dcvc_up2": [vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, f32, vp],
+    "dcvc_down2": [vp, i32, vp, i32, i32, i32, i32, i32, f32, i32, vp],
+    "dcvc_maxpool2": [vp, i32, vp, i32, i32, i32, i32, i32, vp],
+    "dcvc_copy_channels": [vp, i32, vp, i32, i64, i32, vp],
+    "dcvc_nchw_to_nhwc": [vp, vp, i32, i32, i32, i32, i32, vp],
+    "dcvc_nhwc_to_nchw": [vp, i32, vp, i32, i32, i32, i32, i32, vp],
+    "dcvc_channel_mean": [vp, i32, vp, vp, i32, i32, i32, vp],
+    "dcvc_se_gate": [vp, vp, vp, vp, i32, i32, i32, vp],
+    "dcvc_scale_channels": [vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, vp],
+    "dcvc_round_symbols": [vp, i32, vp, i32, vp, i32, i32, i32, i32, vp],
+    "dcvc_symbols_to_nhwc": [vp, vp, i32, i32, i32, i32, i32, vp],
+    "dcvc_dual_prior_enc": [C.POINTER(DualPriorArgs), vp],
+    "dcvc_dual_prior_dec_index": [C.POINTER(DualPriorArgs), vp],
+    "dcvc_dual_prior_dec_apply": [C.POINTER(DualPriorArgs), vp],
+    "dcvc_scale_bits": [vp, vp, vp, vp, i32, i32, i64, vp],
+    "dcvc_factorized_bits": [vp, i32, vp, vp, vp, i32, i32, i32, vp],
+    "dcvc_sq_err": [vp, i32, vp, i32, vp, vp, i32, i32, i32, vp],
+}
+
+HIP_SYMBOLS = sorted(list(_SIGS) + ["dcvc_conv_pack_size", "dcvc_hip_version"])
+RANS_SYMBOLS = [
+    "dcvc_rans_encoder_create", "dcvc_rans_encoder_destroy", "dcvc_rans_encoder_reset",
+    "dcvc_rans_encoder_encode_with_indexes", "dcvc_rans_encoder_flush_bound", "dcvc_rans_encoder_flush",
+    "dcvc_rans_decoder_create", "dcvc_rans_decoder_destroy", "dcvc_rans_decoder_set_stream",
+    "dcvc_rans_decoder_decode_stream", "dcvc_pmf_to_quantized_cdf",
+]
+
+
+def hip():
+    global _hip
+    if _hip is None:
+        L = _load("libdcvc_hip.so")
+        for name, sig in _SIGS.items():
+            fn = getattr(L, name)
+            fn.argtypes = sig
+            fn.restype = C.c_int
+        L.dcvc_conv_pack_size.argtypes = [i32, i32, i32, vp, C.POINTER(i32)]
+        L.dcvc_conv_pack_size.restype = i64
+        L.dcvc_hip_version.restype = C.c_char_p
+        _hip = L
+    return _hip
+
+
+def check(code, what):
+    if code != 0:
+        raise KernelError(f"{what} failed with status {code}")
