@@ -73,12 +73,14 @@ typedef struct {
     /* output */
     float *out;           /* (N, Hout*ps, Wout*ps, out_cs) where ps = pixel_shuffle ? 2 : 1 */
     int32_t out_cs;
-    int32_t out_act;      /* 0: none, 1: LeakyReLU(out_slope) after bias */
+    int32_t out_act;      /* 0: none, 1: LeakyReLU(out_slope) after bias, 2: clamp to [0, 1] */
     float out_slope;
     int32_t pixel_shuffle;/* 1: write PixelShuffle(2) of the result (Cout % 4 == 0) */
     const float *res;     /* optional residual added after the activation, laid out like out */
     int32_t res_cs;
     const float *res_gate;/* optional (N, Cfinal) per-sample per-channel factor on res (SE gate) */
+    const float *res2;    /* optional second residual, added last: out = res2 + (act(conv) + res) */
+    int32_t res2_cs;
 } dcvc_conv_args;
 
 /* Number of floats dcvc_conv_pack_weights writes to wpack for this geometry, and the padded

@@ -56,6 +56,8 @@ struct ConvK {
     const float *res;
     int res_cs;
     const float *res_gate;
+    const float *res2;
+    int res2_cs;
 };
 
 __device__ __forceinline__ float act(float v, float slope) { return v > 0.f ? v : v * slope; }
@@ -176,7 +178,8 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_f32(const ConvK a) {
                 const int ox = x0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
                 if (ox >= a.Wout) continue;
                 float v = acc[m][n][r] + bias;
-                if (a.out_act) v = act(v, a.out_slope);
+                if (a.out_act == 1) v = act(v, a.out_slope);
+                else if (a.out_act == 2) v = fminf(fmaxf(v, 0.f), 1.f);
                 const size_t pix = a.ps ? ((size_t)(img * Ho + 2 * oy + dy) * Wo + 2 * ox + dx)
                                         : ((size_t)(img * Ho + oy) * Wo + ox);
                 if (a.res) {
@@ -184,6 +187,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_f32(const ConvK a) {
                     if (a.res_gate) rv *= gate;
                     v += rv;
                 }
+                if (a.res2) v = a.res2[pix * a.res2_cs + cf] + v;
                 a.out[pix * a.out_cs + cf] = v;
             }
         }
@@ -283,6 +287,8 @@ extern "C" int dcvc_conv2d(const dcvc_conv_args *a, void *stream) {
     k.res = a->res;
     k.res_cs = a->res_cs;
     k.res_gate = a->res_gate;
+    k.res2 = a->res2;
+    k.res2_cs = a->res2_cs;
     hipStream_t st = (hipStream_t)stream;
     const bool wide = (a->Cout_pad % 64) == 0;
     const int key = a->ks * 10 + a->stride;

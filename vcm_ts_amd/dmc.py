@@ -1,0 +1,411 @@
+"""``DMC`` -- the P-frame codec of DCVC-HEM behind the reference's operator API, running on
+the hand-written gfx950 kernels of libdcvc_hip.so.
+
+Drop-in surface (same method names, argument meaning, result keys and state-dict key names
+as /root/reference/DCVC_HEM/src/models/video_model.py:131-596 and its base class
+src/models/common_model.py:14-217):
+
+    DMC(anchor_num=4)
+    .forward_one_frame(x, dpb, mv_y_q_scale=None, y_q_scale=None) / .forward(...)   :470-596
+    .compress(x, dpb, mv_y_q_scale, y_q_scale) -> {"dbp", "bit_stream"}              :263-352
+    .decompress(dpb, string, height, width, mv_y_q_scale, y_q_scale) -> {"dpb"}      :354-422
+    .encode_decode(x, dpb, output_path=None, pic_width=None, pic_height=None, ...)   :424-468
+    .update(force=False)                                                             common_model.py:75-80
+    DMC.get_q_scales_from_ckpt(path)                                                 :248-253
+
+Differences that are deliberate and documented in DESIGN.md: tensors in the returned DPB
+are zero-copy logical-NCHW views over channels-last device buffers that the next call
+recycles (two alternating sets); inference only (no autograd through the HIP kernels in
+this round); ``compress`` also returns the key ``"dpb"`` next to the reference's misspelt
+``"dbp"``.
+"""
+from __future__ import annotations
+
+import time
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import entropy as E
+from . import stream as S
+from .engine import Engine, View
+from .nets import Net
+from .params import dmc_spec, seeded_state_dict
+
+
+class _Holder(nn.Module):
+    """Empty container used to rebuild the reference's dotted parameter names."""
+
+
+def build_param_tree(root: nn.Module, spec, init):
+    for name, shape in spec.items():
+        parts = name.split(".")
+        m = root
+        for p in parts[:-1]:
+            if p not in m._modules:
+                m.add_module(p, _Holder())
+            m = m._modules[p]
+        t = init[name]
+        assert tuple(t.shape) == tuple(shape), name
+        m.register_parameter(parts[-1], nn.Parameter(t.clone(), requires_grad=False))
+
+
+class CodecBase(nn.Module):
+    """What DMC and IntraNoAR share: parameter tree, engine, q-scale plumbing, tables."""
+
+    _tag = "codec"
+
+    def __init__(self, spec, seed=0):
+        super().__init__()
+        build_param_tree(self, spec, seeded_state_dict(spec, seed=seed))
+        self._pmap = dict(self.named_parameters())
+        self._engine = None
+        self._net = None
+        self.entropy_coder = None
+        self._tables = None
+        self._flip = 0
+
+    # -- plumbing ------------------------------------------------------------------------
+    def P(self, name):
+        return self._pmap[name]
+
+    @property
+    def device(self):
+        return self._pmap[next(iter(self._pmap))].device
+
+    def engine(self) -> Engine:
+        dev = self.device
+        if self._engine is None or self._engine.device != dev:
+            self._engine = Engine(dev)  # raises without a GPU / without libdcvc_hip.so
+            self._net = Net(self._engine, self.P, self._tag)
+        return self._engine
+
+    def _qvec(self, q, N, default_param=None):
+        """q-scale argument (None | float | 0-d / (N,1,1,1) tensor) -> (N,) fp32 device tensor."""
+        if q is None:
+            q = self.P(default_param)
+        if torch.is_tensor(q):
+            q = q.detach().to(device=self.device, dtype=torch.float32).reshape(-1)
+            if q.numel() == 1:
+                q = q.expand(N)
+            assert q.numel() == N, "one q-scale per batch element"
+            return q.contiguous()
+        return torch.full((N,), float(q), dtype=torch.float32, device=self.device)
+
+    def _frame_in(self, name, x, cs=None) -> View:
+        e = self.engine()
+        N, C_, H, W = x.shape
+        return e.from_nchw(x, e.buf(f"{self._tag}/{name}", N, H, W, C_, cs=cs))
+
+    def _dpb_in(self, name, t) -> View:
+        """Reference tensors handed in by the caller: ours are aliased, foreign ones converted."""
+        if t is None:
+            return None
+        v = View.alias(t) if t.device == self.device else None
+        return v if v is not None else self._frame_in("in_" + name, t)
+
+    def _out_set(self, *inputs):
+        """Pick the DPB buffer set (0/1) that none of the caller's tensors aliases."""
+        e = self.engine()
+        for k in (self._flip, 1 - self._flip):
+            ptrs = {t.data_ptr() for key, t in e.bufs.items() if key[0].startswith(f"{self._tag}/dpb{k}.")}
+            if not any(v is not None and v.ptr in ptrs for v in inputs):
+                self._flip = 1 - k
+                return k
+        raise RuntimeError("both DPB buffer sets are aliased by the inputs")
+
+    # -- entropy tables ------------------------------------------------------------------
+    _distribution = "laplace"
+    _z_names = ("bit_estimator_z",)
+
+    def update(self, force=False):
+        if self.entropy_coder is not None and not force:
+            return
+        self.entropy_coder = E.EntropyCoder()
+        sd = {k: v for k, v in self._pmap.items()}
+        t = {"scale": E.scale_table_cdfs(self._distribution)}
+        for n in self._z_names:
+            t[n] = E.factorized_cdfs(E.factorized_params(sd, n))
+        self._tables = t
+
+    def _zblock(self, name):
+        key = ("zblock", name)
+        ver = tuple(self.P(f"{name}.f{i}.h")._version for i in (1, 2, 3, 4))
+        c = self.engine().packs.get(key)
+        if c is None or c[0] != ver:
+            blk = E.factorized_param_block(E.factorized_params(self._pmap, name)).to(self.device)
+            c = (ver, blk)
+            self.engine().packs[key] = c
+        return c[1]
+
+    # -- host <-> device symbol traffic ---------------------------------------------------
+    def _encode_factorized(self, name, sym: torch.Tensor, N, C_, H, W):
+        cdf, ln, off = self._tables[name]
+        s = sym.cpu().numpy()
+        idx = np.broadcast_to(np.arange(C_, dtype=np.int32)[None, :, None, None], (N, C_, H, W)).reshape(-1)
+        self.entropy_coder.encode_with_indexes(s, idx, cdf, ln, off)
+
+    def _encode_scale(self, sym: torch.Tensor, idx: torch.Tensor):
+        cdf, ln, off = self._tables["scale"]
+        self.entropy_coder.encode_with_indexes(sym.cpu().numpy(), idx.cpu().numpy(), cdf, ln, off)
+
+    def _decode_factorized(self, name, N, C_, H, W) -> torch.Tensor:
+        cdf, ln, off = self._tables[name]
+        idx = np.broadcast_to(np.arange(C_, dtype=np.int32)[None, :, None, None], (N, C_, H, W)).reshape(-1)
+        out = self.entropy_coder.decoder.decode_stream(idx, cdf, ln, off)
+        return torch.from_numpy(out).to(self.device)
+
+    def _decode_scale(self, idx: torch.Tensor) -> torch.Tensor:
+        cdf, ln, off = self._tables["scale"]
+        out = self.entropy_coder.decoder.decode_stream(idx.cpu().numpy(), cdf, ln, off)
+        return torch.from_numpy(out).to(self.device)
+
+    # -- dual prior (both directions) -----------------------------------------------------
+    def _dual_prior_encode(self, tag, y: View, fusion: View, prior_name, out: View, q_basic, q_scale, want_stats,
+                           want_symbols):
+        """forward_dual_prior (common_model.py:104-177): returns dict with y_q / scales_hat
+        (dense NHWC planes for the bit estimate) and the two (sym, idx) int32 pairs."""
+        e, net = self.engine(), self._net
+        N, H, W, Cc = y.N, y.H, y.W, y.C
+        n = N * H * W * Cc
+        params = net.buf(f"{tag}.dp_params", like=y, C=4 * Cc)
+        y_hat = e.fbuf(f"{self._tag}/{tag}.dp_yhat", n)
+        r = {}
+        if want_stats:
+            r["y_q"] = e.fbuf(f"{self._tag}/{tag}.dp_yq", n)
+            r["scales_hat"] = e.fbuf(f"{self._tag}/{tag}.dp_sh", n)
+        sym = [None, None]
+        idx = [None, None]
+        if want_symbols:
+            for k in (0, 1):
+                sym[k] = e.ibuf(f"{self._tag}/{tag}.sym{k}", n // 2)
+                idx[k] = e.ibuf(f"{self._tag}/{tag}.idx{k}", n // 2)
+        common = dict(y=y, fusion=fusion, params=params, y_hat=y_hat, y_q=r.get("y_q"), scales_hat=r.get("scales_hat"),
+                      distribution=self._distribution)
+        e.dual_prior("enc", 0, sym=sym[0], idx=idx[0], **common)
+        spatial = net.three_convs(prior_name, params)
+        e.dual_prior("enc", 1, spatial=spatial, sym=sym[1], idx=idx[1], out=out, q_basic=q_basic, q_scale=q_scale,
+                     **common)
+        r["sym"], r["idx"] = sym, idx
+        return r
+
+    def _dual_prior_decode(self, tag, fusion: View, prior_name, out: View, q_basic, q_scale):
+        """decompress_dual_prior (common_model.py:182-217): two rANS decodes with the spatial
+        prior in between; everything else stays on the device."""
+        e, net = self.engine(), self._net
+        N, H, W = fusion.N, fusion.H, fusion.W
+        Cc = fusion.C // 3
+        n = N * H * W * Cc
+        params = net.buf(f"{tag}.dp_params", N=N, H=H, W=W, C=4 * Cc)
+        y_hat = e.fbuf(f"{self._tag}/{tag}.dp_yhat", n)
+        idx = e.ibuf(f"{self._tag}/{tag}.idx0", n // 2)
+        common = dict(fusion=fusion, params=params, y_hat=y_hat, distribution=self._distribution)
+        e.dual_prior("dec_index", 0, idx=idx, **common)
+        sym = self._decode_scale(idx)
+        e.dual_prior("dec_apply", 0, sym=sym, **common)
+        spatial = net.three_convs(prior_name, params)
+        e.dual_prior("dec_index", 1, spatial=spatial, idx=idx, **common)
+        sym = self._decode_scale(idx)
+        e.dual_prior("dec_apply", 1, spatial=spatial, sym=sym, out=out, q_basic=q_basic, q_scale=q_scale, **common)
+        return out
+
+
+class DMC(CodecBase):
+    _tag = "dmc"
+    _distribution = "laplace"
+    _z_names = ("bit_estimator_z", "bit_estimator_z_mv")
+
+    def __init__(self, anchor_num=4, seed=0):
+        super().__init__(dmc_spec(anchor_num), seed=seed)
+        self.DMC_version = "1.19"
+        self.anchor_num = int(anchor_num)
+        self.channel_mv, self.channel_N, self.channel_M = 64, 64, 96
+
+    @staticmethod
+    def get_q_scales_from_ckpt(ckpt_path):
+        ckpt = S.get_state_dict(ckpt_path)
+        return ckpt["y_q_scale"].reshape(-1), ckpt["mv_y_q_scale"].reshape(-1)
+
+    # ------------------------------------------------------------------ shared analysis
+    def _mv_side(self, net: Net, dpb_v, mv_y: View, mv_z_hat: View, N, q_mv, k, mode, decode=False):
+        """mv hyper-decoder -> prior fusion -> dual prior -> mv_y_hat (in DPB set k)."""
+        ref_mv_y = dpb_v["ref_mv_y"]
+        mv_params = net.hyper_dec("mv_hyper_prior_decoder", mv_z_hat)
+        if ref_mv_y is None:  # zeros contribute nothing: drop the segment (and its weight slice)
+            fusion = net.three_convs("mv_y_prior_fusion", [mv_params], cin_slice=(0, 128))
+        else:
+            fusion = net.three_convs("mv_y_prior_fusion", [mv_params, ref_mv_y])
+        out = net.buf(f"dpb{k}.ref_mv_y", like=mv_params, C=64)
+        qb = self.P("mv_y_q_basic").reshape(-1)
+        if decode:
+            self._dual_prior_decode("mv", fusion, "mv_y_spatial_prior", out, qb, q_mv)
+            return out, None
+        r = self._dual_prior_encode("mv", mv_y, fusion, "mv_y_spatial_prior", out, qb, q_mv,
+                                    want_stats=(mode == "estimate"), want_symbols=(mode == "compress"))
+        return out, r
+
+    def _y_prior(self, net: Net, dpb_v, c3: View, z_hat: View):
+        hier = net.hyper_dec("contextual_hyper_prior_decoder", z_hat)
+        t = net.conv("temporal_prior_encoder.0", c3, stride=2, out_slope=0.1)
+        temporal = net.conv("temporal_prior_encoder.2", t, stride=2)
+        ref_y = dpb_v["ref_y"]
+        if ref_y is None:
+            return net.three_convs("y_prior_fusion", [temporal, hier], cin_slice=(0, 384))
+        return net.three_convs("y_prior_fusion", [temporal, hier, ref_y])
+
+    def _views_of_dpb(self, dpb):
+        return {k: self._dpb_in(k, dpb.get(k)) for k in ("ref_frame", "ref_feature", "ref_y", "ref_mv_y")}
+
+    def _run(self, x, dpb, mv_y_q_scale, y_q_scale, mode):
+        """mode 'estimate' (forward_one_frame, unclamped recon as video_model.py:535) or
+        'compress' (recon clamped to [0, 1] exactly as the decoder will, :413, so that the
+        encoder's own DPB is bit-identical to the decoder's and no decode pass is needed)."""
+        e = self.engine()
+        net = self._net
+        N, _, H, W = x.shape
+        assert H % 64 == 0 and W % 64 == 0, "pad to a multiple of 64 first (stream.get_padding_size)"
+        q_mv = self._qvec(mv_y_q_scale, N, "mv_y_q_scale")
+        q_y = self._qvec(y_q_scale, N, "y_q_scale")
+        dv = self._views_of_dpb(dpb)
+        k = self._out_set(*dv.values())
+        # current frame lives in channels 0-2 of SpyNet's finest 8-channel input buffer
+        spy0 = e.buf("dmc/spy.in0", N, H, W, 8)
+        x3 = e.from_nchw(x, spy0.slice(0, 3))
+        est_mv = net.spynet(x3, dv["ref_frame"])
+        mv_y_raw = net.encoder_stack("mv_encoder", est_mv)
+        mv_y = e.scale_channels(mv_y_raw, net.buf("mv_y", like=mv_y_raw, C=64), self.P("mv_y_q_basic").reshape(-1), q_mv)
+        mv_z = net.hyper_enc5("mv_hyper_prior_encoder", mv_y)
+        mv_z_hat = net.buf("mv_z_hat", like=mv_z, C=64)
+        sym_mv_z = e.ibuf("dmc/sym_mv_z", N * 64 * mv_z.HW) if mode == "compress" else None
+        e.round_symbols(mv_z, mv_z_hat, sym_mv_z)
+        mv_y_hat, r_mv = self._mv_side(net, dv, mv_y, mv_z_hat, N, q_mv, k, mode)
+        mv_hat = net.decoder_stack("mv_decoder", mv_y_hat)
+        enc_cat2 = net.buf("enc_cat2", N=N, H=H // 2, W=W // 2, C=128)
+        enc_cat3 = net.buf("enc_cat3", N=N, H=H // 4, W=W // 4, C=128)
+        c1, c2, c3, warp_frame = net.motion_compensation(dv["ref_frame"], dv["ref_feature"], mv_hat, enc_cat2, enc_cat3,
+                                                         want_warp_frame=(mode == "estimate"))
+        y_raw = net.contextual_encoder(x3, c1, enc_cat2, enc_cat3)
+        y = e.scale_channels(y_raw, net.buf("y", like=y_raw, C=96), self.P("y_q_basic").reshape(-1), q_y)
+        n_ = "contextual_hyper_prior_encoder"
+        t = net.conv(f"{n_}.0", y, out_slope=0.01)
+        t = net.conv(f"{n_}.2", t, stride=2, out_slope=0.01)
+        z = net.conv(f"{n_}.4", t, stride=2)
+        z_hat = net.buf("z_hat", like=z, C=64)
+        sym_z = e.ibuf("dmc/sym_z", N * 64 * z.HW) if mode == "compress" else None
+        e.round_symbols(z, z_hat, sym_z)
+        fusion = self._y_prior(net, dv, c3, z_hat)
+        y_hat = net.buf(f"dpb{k}.ref_y", like=y, C=96)
+        r_y = self._dual_prior_encode("y", y, fusion, "y_spatial_prior", y_hat, self.P("y_q_basic").reshape(-1), q_y,
+                                      want_stats=(mode == "estimate"), want_symbols=(mode == "compress"))
+        dec_feature = net.contextual_decoder(y_hat, c2, c3)
+        feature = net.buf(f"dpb{k}.ref_feature", N=N, H=H, W=W, C=64)
+        recon = net.buf(f"dpb{k}.ref_frame", N=N, H=H, W=W, C=3)
+        net.recon_generation(dec_feature, c1, feature, recon, clamp=(mode == "compress"))
+        return dict(N=N, H=H, W=W, x3=x3, recon=recon, feature=feature, y_hat=y_hat, mv_y_hat=mv_y_hat,
+                    warp_frame=warp_frame, r_mv=r_mv, r_y=r_y, mv_z_hat=mv_z_hat, z_hat=z_hat, sym_mv_z=sym_mv_z,
+                    sym_z=sym_z, est_mv=est_mv, mv_hat=mv_hat, c1=c1, c2=c2, c3=c3, y=y, mv_y=mv_y)
+
+    @staticmethod
+    def _dpb_out(o):
+        return {"ref_frame": o["recon"].nchw(), "ref_feature": o["feature"].nchw(), "ref_y": o["y_hat"].nchw(),
+                "ref_mv_y": o["mv_y_hat"].nchw()}
+
+    # ------------------------------------------------------------------ public API
+    @torch.no_grad()
+    def forward_one_frame(self, x, dpb, mv_y_q_scale=None, y_q_scale=None):
+        e = self.engine()
+        o = self._run(x, dpb, mv_y_q_scale, y_q_scale, "estimate")
+        N, pix = o["N"], o["H"] * o["W"]
+        mse = e.sq_err(o["x3"], o["recon"]) / pix
+        me_mse = e.sq_err(o["x3"], o["warp_frame"]) / pix
+        per_y = o["y"].HW * 96
+        per_mv = o["mv_y"].HW * 64
+        bpp_y = e.scale_bits(o["r_y"]["y_q"], o["r_y"]["scales_hat"], N, per_y) / pix
+        bpp_mv_y = e.scale_bits(o["r_mv"]["y_q"], o["r_mv"]["scales_hat"], N, per_mv) / pix
+        bpp_z = e.factorized_bits(o["z_hat"], self._zblock("bit_estimator_z")) / pix
+        bpp_mv_z = e.factorized_bits(o["mv_z_hat"], self._zblock("bit_estimator_z_mv")) / pix
+        bpp = bpp_y + bpp_z + bpp_mv_y + bpp_mv_z
+        res = {"bpp_mv_y": bpp_mv_y, "bpp_mv_z": bpp_mv_z, "bpp_y": bpp_y, "bpp_z": bpp_z, "bpp": bpp,
+               "me_mse": me_mse, "mse": mse, "dpb": self._dpb_out(o)}
+        for key, v in (("bit", bpp), ("bit_y", bpp_y), ("bit_z", bpp_z), ("bit_mv_y", bpp_mv_y), ("bit_mv_z", bpp_mv_z)):
+            res[key] = torch.sum(v) * pix
+        res["_views"] = o
+        return res
+
+    def forward(self, x, dpb, mv_y_q_scale=None, y_q_scale=None):
+        return self.forward_one_frame(x, dpb, mv_y_q_scale=mv_y_q_scale, y_q_scale=y_q_scale)
+
+    @torch.no_grad()
+    def compress(self, x, dpb, mv_y_q_scale, y_q_scale):
+        if self.entropy_coder is None:
+            raise RuntimeError("call update() before compress()/decompress()")
+        o = self._run(x, dpb, mv_y_q_scale, y_q_scale, "compress")
+        N = o["N"]
+        assert N == 1, "the bitstream format carries one picture per stream (video_model.py:333-340)"
+        ec = self.entropy_coder
+        ec.reset_encoder()
+        zs = o["mv_z_hat"]
+        self._encode_factorized("bit_estimator_z_mv", o["sym_mv_z"], N, 64, zs.H, zs.W)
+        for kk in (0, 1):
+            self._encode_scale(o["r_mv"]["sym"][kk], o["r_mv"]["idx"][kk])
+        zs = o["z_hat"]
+        self._encode_factorized("bit_estimator_z", o["sym_z"], N, 64, zs.H, zs.W)
+        for kk in (0, 1):
+            self._encode_scale(o["r_y"]["sym"][kk], o["r_y"]["idx"][kk])
+        bit_stream = ec.flush_encoder()
+        d = self._dpb_out(o)
+        return {"dbp": d, "dpb": d, "bit_stream": bit_stream, "_views": o}
+
+    @torch.no_grad()
+    def decompress(self, dpb, string, height, width, mv_y_q_scale, y_q_scale):
+        if self.entropy_coder is None:
+            raise RuntimeError("call update() before compress()/decompress()")
+        e = self.engine()
+        net = self._net
+        N = 1
+        q_mv = self._qvec(mv_y_q_scale, N, "mv_y_q_scale")
+        q_y = self._qvec(y_q_scale, N, "y_q_scale")
+        dv = self._views_of_dpb(dpb)
+        k = self._out_set(*dv.values())
+        self.entropy_coder.set_stream(string)
+        zh, zw = S.get_downsampled_shape(height, width, 64)
+        H, W = zh * 64, zw * 64
+        sym = self._decode_factorized("bit_estimator_z_mv", N, 64, zh, zw)
+        mv_z_hat = e.symbols_to_nhwc(sym, net.buf("mv_z_hat", N=N, H=zh, W=zw, C=64))
+        mv_y_hat, _ = self._mv_side(net, dv, None, mv_z_hat, N, q_mv, k, "decode", decode=True)
+        mv_hat = net.decoder_stack("mv_decoder", mv_y_hat)
+        enc_cat2 = net.buf("enc_cat2", N=N, H=H // 2, W=W // 2, C=128)
+        enc_cat3 = net.buf("enc_cat3", N=N, H=H // 4, W=W // 4, C=128)
+        c1, c2, c3, _ = net.motion_compensation(dv["ref_frame"], dv["ref_feature"], mv_hat, enc_cat2, enc_cat3, False)
+        sym = self._decode_factorized("bit_estimator_z", N, 64, zh, zw)
+        z_hat = e.symbols_to_nhwc(sym, net.buf("z_hat", N=N, H=zh, W=zw, C=64))
+        fusion = self._y_prior(net, dv, c3, z_hat)
+        y_hat = net.buf(f"dpb{k}.ref_y", N=N, H=H // 16, W=W // 16, C=96)
+        self._dual_prior_decode("y", fusion, "y_spatial_prior", y_hat, self.P("y_q_basic").reshape(-1), q_y)
+        dec_feature = net.contextual_decoder(y_hat, c2, c3)
+        feature = net.buf(f"dpb{k}.ref_feature", N=N, H=H, W=W, C=64)
+        recon = net.buf(f"dpb{k}.ref_frame", N=N, H=H, W=W, C=3)
+        net.recon_generation(dec_feature, c1, feature, recon, clamp=True)  # recon.clamp(0, 1), :413
+        o = dict(recon=recon, feature=feature, y_hat=y_hat, mv_y_hat=mv_y_hat)
+        return {"dpb": self._dpb_out(o)}
+
+    def encode_decode(self, x, dpb, output_path=None, pic_width=None, pic_height=None, mv_y_q_scale=None,
+                      y_q_scale=None):
+        if output_path is not None:
+            mv_y_q_scale, mv_y_q_index = S.get_rounded_q(mv_y_q_scale)
+            y_q_scale, y_q_index = S.get_rounded_q(y_q_scale)
+            t0 = time.time()
+            encoded = self.compress(x, dpb, mv_y_q_scale, y_q_scale)
+            S.encode_p(encoded["bit_stream"], mv_y_q_index, y_q_index, output_path)
+            bits = S.filesize(output_path) * 8
+            t1 = time.time()
+            mv_y_q_index, y_q_index, string = S.decode_p(output_path)
+            decoded = self.decompress(dpb, string, pic_height, pic_width, mv_y_q_index / 100, y_q_index / 100)
+            torch.cuda.synchronize(self.device)
+            t2 = time.time()
+            return {"dpb": decoded["dpb"], "bit": bits, "encoding_time": t1 - t0, "decoding_time": t2 - t1}
+        enc = self.forward_one_frame(x, dpb, mv_y_q_scale=mv_y_q_scale, y_q_scale=y_q_scale)
+        return {"dpb": enc["dpb"], "bit_y": enc["bit_y"].item(), "bit_z": enc["bit_z"].item(),
+                "bit_mv_y": enc["bit_mv_y"].item(), "bit_mv_z": enc["bit_mv_z"].item(), "bit": enc["bit"].item(),
+                "decoding_time": 0}

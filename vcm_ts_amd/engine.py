@@ -1,0 +1,324 @@
+"""Device-side plumbing: strided-NHWC buffer views, a named workspace, packed-weight cache
+and thin Python wrappers over the C ABI of include/dcvc_hip.h.
+
+PyTorch is used for exactly three things here: allocating HBM (torch.empty on the GPU),
+naming the HIP stream kernels are enqueued on (torch.cuda.current_stream) and exposing
+results as tensors.  All arithmetic on the product path happens in libdcvc_hip.so; there is
+no eager/CPU fallback -- without the library or without a GPU the constructors raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+
+from . import lib
+
+
+def _r4(c):
+    return (c + 3) // 4 * 4
+
+
+class View:
+    """C channels starting at channel `coff` of an (N, H, W, cs) fp32 buffer."""
+
+    __slots__ = ("base", "N", "H", "W", "C", "cs", "coff", "ptr")
+
+    def __init__(self, base: torch.Tensor, C_: int, coff: int = 0, geom=None):
+        self.base = base
+        if geom is None:
+            assert base.dim() == 4 and base.dtype == torch.float32 and base.is_contiguous()
+            self.N, self.H, self.W, self.cs = base.shape
+            self.ptr = base.data_ptr() + 4 * coff
+        else:  # foreign channels-last tensor: (N, H, W, cs, ptr); `base` only keeps it alive
+            self.N, self.H, self.W, self.cs, self.ptr = geom
+        self.C = C_
+        self.coff = coff
+        assert coff + C_ <= self.cs
+
+    @staticmethod
+    def alias(t: torch.Tensor):
+        """View over a logical-NCHW tensor whose memory already is strided NHWC (one of our own
+        outputs handed back by the caller), or None if its layout does not qualify."""
+        if t.dim() != 4 or t.dtype != torch.float32 or not t.is_cuda:
+            return None
+        N, C_, H, W = t.shape
+        cs = t.stride(3)
+        if t.stride(1) == 1 and cs >= C_ and cs % 4 == 0 and t.stride(2) == W * cs and t.stride(0) == H * W * cs \
+                and t.data_ptr() % 16 == 0:
+            return View(t, C_, 0, geom=(N, H, W, cs, t.data_ptr()))
+        return None
+
+    def slice(self, c0: int, c: int) -> "View":
+        v = View(self.base, c, 0, geom=(self.N, self.H, self.W, self.cs, self.ptr + 4 * c0))
+        v.coff = self.coff + c0
+        return v
+
+    def nchw(self) -> torch.Tensor:
+        """Zero-copy logical (N, C, H, W) tensor over this view (channels-last strides)."""
+        return self.base[..., self.coff : self.coff + self.C].permute(0, 3, 1, 2)
+
+    @property
+    def HW(self):
+        return self.H * self.W
+
+    def __repr__(self):
+        return f"View(N={self.N},H={self.H},W={self.W},C={self.C},cs={self.cs},coff={self.coff})"
+
+
+class PackedConv:
+    __slots__ = ("w", "b", "ks", "Cout", "Cout_pad", "seg_C", "ps", "version")
+
+
+class Engine:
+    def __init__(self, device):
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("the HIP engine needs a GPU device (no CPU fallback exists)")
+        self.L = lib.hip()
+        self.bufs = {}
+        self.packs = {}
+        self.calls = 0
+
+    # ------------------------------------------------------------------ memory
+    def stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def buf(self, name, N, H, W, C_, cs=None, zero=False) -> View:
+        cs = cs or _r4(C_)
+        key = (name, N, H, W, cs)
+        t = self.bufs.get(key)
+        if t is None:
+            t = (torch.zeros if zero else torch.empty)((N, H, W, cs), dtype=torch.float32, device=self.device)
+            self.bufs[key] = t
+        return View(t, C_)
+
+    def ibuf(self, name, n) -> torch.Tensor:
+        key = (name, n, "i32")
+        t = self.bufs.get(key)
+        if t is None:
+            t = torch.empty(n, dtype=torch.int32, device=self.device)
+            self.bufs[key] = t
+        return t
+
+    def fbuf(self, name, n) -> torch.Tensor:
+        key = (name, n, "f32")
+        t = self.bufs.get(key)
+        if t is None:
+            t = torch.empty(n, dtype=torch.float32, device=self.device)
+            self.bufs[key] = t
+        return t
+
+    def release(self):
+        self.bufs.clear()
+
+    def bytes_reserved(self):
+        return sum(t.numel() * t.element_size() for t in self.bufs.values())
+
+    # ------------------------------------------------------------------ boundary layout
+    def from_nchw(self, x: torch.Tensor, out: View) -> View:
+        """NCHW (any strides) -> out view.  A tensor that already is one of our channels-last
+        views is still copied: callers own their tensors and may mutate them."""
+        N, C_, H, W = x.shape
+        assert (out.N, out.H, out.W, out.C) == (N, H, W, C_), (x.shape, out)
+        x = x.detach()
+        if x.device != self.device or x.dtype != torch.float32:
+            x = x.to(device=self.device, dtype=torch.float32)
+        cs = x.stride(3) if x.dim() == 4 else 0
+        if x.stride(1) == 1 and cs >= C_ and cs % 4 == 0 and x.stride(2) == W * cs and x.stride(0) == H * W * cs \
+                and x.data_ptr() % 16 == 0:
+            lib.check(self.L.dcvc_copy_channels(x.data_ptr(), cs, out.ptr, out.cs, N * H * W, C_, self.stream()),
+                      "copy_channels")
+        else:
+            x = x.contiguous()
+            lib.check(self.L.dcvc_nchw_to_nhwc(x.data_ptr(), out.ptr, out.cs, N, C_, H, W, self.stream()),
+                      "nchw_to_nhwc")
+        self.calls += 1
+        return out
+
+    def to_nchw(self, v: View, clamp01=False) -> torch.Tensor:
+        out = torch.empty((v.N, v.C, v.H, v.W), dtype=torch.float32, device=self.device)
+        lib.check(self.L.dcvc_nhwc_to_nchw(v.ptr, v.cs, out.data_ptr(), v.N, v.C, v.H, v.W, int(clamp01),
+                                           self.stream()), "nhwc_to_nchw")
+        return out
+
+    # ------------------------------------------------------------------ convolution
+    def pack(self, key, weight: torch.Tensor, bias, seg_C, ps, cin_slice=None) -> PackedConv:
+        ver = (weight._version, None if bias is None else bias._version, weight.data_ptr())
+        pk = self.packs.get(key)
+        if pk is not None and pk.version == ver:
+            return pk
+        w = weight.detach().float().cpu()
+        if cin_slice is not None:
+            w = w[:, cin_slice[0] : cin_slice[1]]
+        w = w.contiguous().numpy()
+        Cout, Cin, ks, _ = w.shape
+        assert sum(seg_C) == Cin, (key, seg_C, Cin)
+        b = None if bias is None else bias.detach().float().cpu().contiguous().numpy()
+        segs = (C.c_int32 * len(seg_C))(*seg_C)
+        cpad = C.c_int32()
+        n = self.L.dcvc_conv_pack_size(Cout, ks, len(seg_C), segs, C.byref(cpad))
+        if n < 0:
+            raise lib.KernelError(f"conv_pack_size({key})")
+        wp = np.empty(n, np.float32)
+        bp = np.empty(cpad.value, np.float32)
+        lib.check(self.L.dcvc_conv_pack_weights(w.ctypes.data, None if b is None else b.ctypes.data, Cout, ks,
+                                                len(seg_C), segs, int(ps), wp.ctypes.data, bp.ctypes.data),
+                  f"conv_pack_weights({key})")
+        pk = PackedConv()
+        pk.w = torch.from_numpy(wp).to(self.device)
+        pk.b = torch.from_numpy(bp).to(self.device)
+        pk.ks, pk.Cout, pk.Cout_pad, pk.seg_C, pk.ps, pk.version = ks, Cout, cpad.value, tuple(seg_C), bool(ps), ver
+        self.packs[key] = pk
+        return pk
+
+    def conv(self, pk: PackedConv, srcs, out: View, stride=1, in_slope=None, out_slope=None, res: View = None,
+             gate: torch.Tensor = None, res2: View = None):
+        a = lib.ConvArgs()
+        assert len(srcs) == len(pk.seg_C)
+        s0 = srcs[0]
+        for i, (s, c) in enumerate(zip(srcs, pk.seg_C)):
+            assert s.C == c and (s.N, s.H, s.W) == (s0.N, s0.H, s0.W), (s, c)
+            a.seg[i].ptr, a.seg[i].C, a.seg[i].cs = s.ptr, s.C, s.cs
+        a.nseg, a.N, a.Hin, a.Win = len(srcs), s0.N, s0.H, s0.W
+        a.in_act, a.in_slope = (0, 0.0) if in_slope is None else (1, in_slope)
+        a.wpack, a.bpack = pk.w.data_ptr(), pk.b.data_ptr()
+        a.ks, a.stride, a.Cout, a.Cout_pad = pk.ks, stride, pk.Cout, pk.Cout_pad
+        pad = pk.ks // 2
+        Ho = (s0.H + 2 * pad - pk.ks) // stride + 1
+        Wo = (s0.W + 2 * pad - pk.ks) // stride + 1
+        m = 2 if pk.ps else 1
+        cfin = pk.Cout // 4 if pk.ps else pk.Cout
+        assert (out.N, out.H, out.W, out.C) == (s0.N, Ho * m, Wo * m, cfin), (out, Ho, Wo, cfin)
+        a.out, a.out_cs = out.ptr, out.cs
+        a.out_act, a.out_slope = (0, 0.0) if out_slope is None else ((2, 0.0) if out_slope == "clamp01" else (1, out_slope))
+        a.pixel_shuffle = int(pk.ps)
+        if res is not None:
+            assert (res.N, res.H, res.W, res.C) == (out.N, out.H, out.W, out.C)
+            a.res, a.res_cs = res.ptr, res.cs
+        if gate is not None:
+            a.res_gate = gate.data_ptr()
+        if res2 is not None:
+            assert (res2.N, res2.H, res2.W, res2.C) == (out.N, out.H, out.W, out.C)
+            a.res2, a.res2_cs = res2.ptr, res2.cs
+        lib.check(self.L.dcvc_conv2d(C.byref(a), self.stream()), "conv2d")
+        self.calls += 1
+        return out
+
+    # ------------------------------------------------------------------ resampling
+    def warp(self, src: View, flow: View, out: View):
+        lib.check(self.L.dcvc_warp(src.ptr, src.cs, flow.ptr, flow.cs, out.ptr, out.cs, src.N, src.H, src.W, src.C,
+                                   self.stream()), "warp")
+        self.calls += 1
+        return out
+
+    def up2(self, src: View, out: View, scale=1.0, out2: View = None):
+        lib.check(self.L.dcvc_up2(src.ptr, src.cs, out.ptr, out.cs, out2.ptr if out2 else None,
+                                  out2.cs if out2 else 0, src.N, src.H, src.W, src.C, scale, self.stream()), "up2")
+        self.calls += 1
+        return out
+
+    def down2(self, src: View, out: View, scale=1.0, avgpool_order=False):
+        lib.check(self.L.dcvc_down2(src.ptr, src.cs, out.ptr, out.cs, src.N, src.H, src.W, src.C, scale,
+                                    int(avgpool_order), self.stream()), "down2")
+        self.calls += 1
+        return out
+
+    def maxpool2(self, src: View, out: View):
+        lib.check(self.L.dcvc_maxpool2(src.ptr, src.cs, out.ptr, out.cs, src.N, src.H, src.W, src.C, self.stream()),
+                  "maxpool2")
+        self.calls += 1
+        return out
+
+    def copy(self, src: View, out: View):
+        lib.check(self.L.dcvc_copy_channels(src.ptr, src.cs, out.ptr, out.cs, src.N * src.H * src.W, src.C,
+                                            self.stream()), "copy_channels")
+        self.calls += 1
+        return out
+
+    # ------------------------------------------------------------------ SE
+    def se_gate(self, name, t: View, w1: torch.Tensor, w2: torch.Tensor) -> torch.Tensor:
+        N, C_ = t.N, t.C
+        scratch = self.fbuf("se_scratch", N * 256 * 256)
+        mean = self.fbuf(name + ".mean", N * C_)
+        gate = self.fbuf(name + ".gate", N * C_)
+        lib.check(self.L.dcvc_channel_mean(t.ptr, t.cs, mean.data_ptr(), scratch.data_ptr(), N, t.HW, C_,
+                                           self.stream()), "channel_mean")
+        lib.check(self.L.dcvc_se_gate(mean.data_ptr(), w1.data_ptr(), w2.data_ptr(), gate.data_ptr(), N, C_,
+                                      w1.shape[0], self.stream()), "se_gate")
+        self.calls += 2
+        return gate
+
+    # ------------------------------------------------------------------ entropy-model elementwise
+    def scale_channels(self, src: View, out: View, q_basic, q_scale, multiply=False):
+        lib.check(self.L.dcvc_scale_channels(src.ptr, src.cs, out.ptr, out.cs, q_basic.data_ptr(), q_scale.data_ptr(),
+                                             int(multiply), src.N, src.HW, src.C, self.stream()), "scale_channels")
+        self.calls += 1
+        return out
+
+    def round_symbols(self, z: View, z_hat: View, sym: torch.Tensor = None):
+        lib.check(self.L.dcvc_round_symbols(z.ptr, z.cs, z_hat.ptr if z_hat else None, z_hat.cs if z_hat else 0,
+                                            sym.data_ptr() if sym is not None else None, z.N, z.H, z.W, z.C,
+                                            self.stream()), "round_symbols")
+        self.calls += 1
+
+    def symbols_to_nhwc(self, sym: torch.Tensor, out: View):
+        lib.check(self.L.dcvc_symbols_to_nhwc(sym.data_ptr(), out.ptr, out.cs, out.N, out.H, out.W, out.C,
+                                              self.stream()), "symbols_to_nhwc")
+        self.calls += 1
+        return out
+
+    def dual_prior(self, mode, step, *, y: View = None, fusion: View, spatial: View = None, params: View,
+                   y_hat: torch.Tensor, y_q=None, y_res=None, scales_hat=None, sym=None, idx=None, out: View = None,
+                   q_basic=None, q_scale=None, distribution="laplace"):
+        a = lib.DualPriorArgs()
+        Cc = fusion.C // 3
+        if y is not None:
+            a.y, a.y_cs = y.ptr, y.cs
+        a.fusion, a.fusion_cs = fusion.ptr, fusion.cs
+        if spatial is not None:
+            a.spatial, a.spatial_cs = spatial.ptr, spatial.cs
+        a.params, a.params_cs = params.ptr, params.cs
+        a.y_hat = y_hat.data_ptr()
+        for nm, t in (("y_q", y_q), ("y_res", y_res), ("scales_hat", scales_hat), ("sym", sym), ("idx", idx),
+                      ("q_basic", q_basic), ("q_scale", q_scale)):
+            if t is not None:
+                setattr(a, nm, t.data_ptr())
+        if out is not None:
+            a.out, a.out_cs = out.ptr, out.cs
+        a.N, a.H, a.W, a.C, a.step = fusion.N, fusion.H, fusion.W, Cc, step
+        smin = 0.01 if distribution == "laplace" else 0.11
+        a.log_scale_min = math.log(smin)
+        a.log_scale_step = (math.log(64.0) - math.log(smin)) / 255
+        fn = {"enc": self.L.dcvc_dual_prior_enc, "dec_index": self.L.dcvc_dual_prior_dec_index,
+              "dec_apply": self.L.dcvc_dual_prior_dec_apply}[mode]
+        lib.check(fn(C.byref(a), self.stream()), "dual_prior_" + mode)
+        self.calls += 1
+
+    def _scratch(self, N):
+        return self.fbuf("reduce_scratch", N * 1024)
+
+    def scale_bits(self, y_q, scales_hat, N, per_sample, gaussian=False) -> torch.Tensor:
+        out = torch.empty(N, dtype=torch.float32, device=self.device)
+        lib.check(self.L.dcvc_scale_bits(y_q.data_ptr(), scales_hat.data_ptr(), out.data_ptr(),
+                                         self._scratch(N).data_ptr(), int(gaussian), N, per_sample, self.stream()),
+                  "scale_bits")
+        self.calls += 2
+        return out
+
+    def factorized_bits(self, z_hat: View, pblock: torch.Tensor) -> torch.Tensor:
+        out = torch.empty(z_hat.N, dtype=torch.float32, device=self.device)
+        lib.check(self.L.dcvc_factorized_bits(z_hat.ptr, z_hat.cs, pblock.data_ptr(), out.data_ptr(),
+                                              self._scratch(z_hat.N).data_ptr(), z_hat.N, z_hat.HW, z_hat.C,
+                                              self.stream()), "factorized_bits")
+        self.calls += 2
+        return out
+
+    def sq_err(self, a: View, b: View) -> torch.Tensor:
+        out = torch.empty(a.N, dtype=torch.float32, device=self.device)
+        lib.check(self.L.dcvc_sq_err(a.ptr, a.cs, b.ptr, b.cs, out.data_ptr(), self._scratch(a.N).data_ptr(), a.N,
+                                     a.HW, a.C, self.stream()), "sq_err")
+        self.calls += 2
+        return out
