@@ -1,0 +1,178 @@
+"""bench.py -- encoded frames/s at 1920x1080, GOP 32 (BASELINE.json metric) on N MI355X.
+
+One "step" = one GOP of 32 synthetic 1920x1080 frames (1 I + 31 P pictures, padded to
+1088x1920) through the real encode path: all networks on the HIP kernels, symbol planes to the
+host, rANS coding into the payload bytes, DPB kept on the device.  Inputs are resident in HBM
+before the timed region.  With N > 1 every rank encodes its own GOPs (GOPs are independent:
+weak scaling, no data-path collective); the timed region is bracketed by barriers and the
+slowest rank's time is used.
+
+Prints ONE JSON line (see the task contract) with two extra objects:
+  roofline     achieved TFLOP/s of the dominant kernel (3x3 stride-1 fp32-MFMA convolution),
+               = algorithmic conv FLOPs of its launches / their summed HIP-event durations,
+               measured live on the launch stream in one extra (untimed) P picture
+  cpu_baseline the CPU oracle (oracle/dcvc_ref.py, a torch-CPU port of the reference path)
+               timed on this box's host cores on a bounded sample (rank 0, N=1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+
+
+def synth_sequence(dev, n, h, w, seed):
+    """n frames (1,3,h,w) on the device: smooth field + global motion + noise (synthetic.py
+    gives the base picture; the per-frame shifts are done on the device to keep start-up short)."""
+    from vcm_ts_amd.synthetic import frames
+
+    base = torch.from_numpy(frames(seed, 1, h, w)[0]).to(dev)
+    g = torch.Generator(device=dev).manual_seed(seed)
+    out = []
+    for t in range(n):
+        f = torch.roll(base, shifts=(t, -2 * t), dims=(1, 2))
+        f = (f + torch.randn(f.shape, generator=g, device=dev) / 255.0).clamp_(0, 1)
+        out.append(f[None].contiguous())
+    return out
+
+
+def host_cores():
+    """CPU threads this process may really use: cgroup quota if set, else affinity, and never
+    more than the 16-core host share a 1-GPU box is given."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(p))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, 16))
+
+
+def cpu_baseline(h, w, threads):
+    """One 1088x1920 P-picture through the CPU oracle's networks (dmc_analysis) = the nets of
+    DMC.compress; bounded sample so the default run stays within minutes."""
+    from oracle import dcvc_ref as R
+    from vcm_ts_amd.params import dmc_spec, seeded_state_dict
+    from vcm_ts_amd.synthetic import frames
+
+    torch.set_num_threads(threads)
+    wd = seeded_state_dict(dmc_spec())
+    fr = frames(7, 2, h, w)
+    x0, x1 = torch.from_numpy(fr[0:1]), torch.from_numpy(fr[1:2])
+    dpb = {"ref_frame": x0, "ref_feature": None, "ref_y": None, "ref_mv_y": None}
+    with torch.no_grad():
+        t0 = time.time()
+        R.dmc_analysis(wd, x1, dpb, 1.0, 1.0)
+        dt = time.time() - t0
+    return dt
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--gop", type=int, default=32)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-size", type=int, nargs=2, default=None, help="H W of the CPU sample (default: padded full size)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", init_method="env://")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+
+    from vcm_ts_amd.dmc import DMC
+    from vcm_ts_amd.intra import IntraNoAR
+    from vcm_ts_amd.pipeline import GopEncoder, pad_frame
+
+    i_net, p_net = IntraNoAR().to(dev).eval(), DMC().to(dev).eval()
+    enc = GopEncoder(i_net, p_net, gop_size=args.gop)
+    seq = [pad_frame(f) for f in synth_sequence(dev, args.gop, args.height, args.width, seed=rank)]
+    q_i, q_mv, q_y = 1.0, 1.0, 1.0
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    bits = 0
+    for _ in range(args.warmup):
+        _, bits, _ = enc.encode_gop(seq, q_i, q_mv, q_y)
+    barrier()
+    t0 = time.time()
+    for _ in range(args.steps):
+        _, bits, _ = enc.encode_gop(seq, q_i, q_mv, q_y)
+    barrier()
+    dt = time.time() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+    frames_total = args.gop * args.steps * world
+    fps = frames_total / dt
+
+    # ---- roofline of the dominant kernel, measured live with HIP events on the launch stream
+    eng = p_net.engine()
+    eng.profile = {}
+    dpb = {"ref_frame": i_net.compress(seq[0], q_i)["x_hat"], "ref_feature": None, "ref_y": None, "ref_mv_y": None}
+    dpb = p_net.compress(seq[1], dpb, q_mv, q_y)["dpb"]
+    p_net.compress(seq[2], dpb, q_mv, q_y)
+    torch.cuda.synchronize(dev)
+    prof = eng.collect_profile()
+    eng.profile = None
+    dom = prof.get("conv3x3s1", {"flops": 0.0, "ms": 1.0, "launches": 0})
+    all_flops = sum(v["flops"] for v in prof.values())
+    all_ms = sum(v["ms"] for v in prof.values())
+    achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
+    roofline = {"bound": "mfma", "kernel": "conv_mfma_f32<3,1,2,*> (3x3 stride-1 convolutions)", "achieved": round(achieved, 2),
+                "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
+                "traffic": None, "launches_per_p_frame": dom["launches"] // 2,
+                "avg_launch_ms": round(dom["ms"] / max(dom["launches"], 1), 4),
+                "all_conv_tflops": round(all_flops / (all_ms * 1e-3) / 1e12, 2),
+                "conv_ms_per_p_frame": round(all_ms / 2, 2)}
+
+    out = {
+        "metric": "encoded frames/sec at 1920x1080 GOP-32", "value": round(fps, 3), "unit": "frames/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "1920x1080 GOP-32 synthetic sequence, single-rate encode (configs[1]); padded 1088x1920; "
+                               "1 I + 31 P pictures per step per GPU; random-init name-seeded weights",
+                   "gop": args.gop, "height": args.height, "width": args.width, "parallelism": f"gop-sharded x{world}",
+                   "bits_per_gop": int(bits), "bpp": round(bits / (args.gop * args.height * args.width), 4)},
+        "roofline": roofline,
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        ph, pw = (args.cpu_size if args.cpu_size else seq[0].shape[-2:])
+        cores = host_cores()
+        sec = cpu_baseline(int(ph), int(pw), cores)
+        out["cpu_baseline"] = {"value": round(1.0 / sec, 5), "unit": "frames/s", "cores": cores, "kind": "port",
+                               "sample": f"1 P picture {ph}x{pw} through the networks of DMC.compress "
+                                         f"(oracle/dcvc_ref.py dmc_analysis, torch-CPU fp32, {cores} threads): {sec:.1f} s"}
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,259 @@
+"""Kernel-level parity through the C ABI (include/dcvc_hip.h) on a real MI355X.
+
+Floating-point kernels are compared with a plain PyTorch fp32 CPU reference of the same op
+(F.conv2d, F.pixel_shuffle, ...), resampling kernels additionally with fixtures produced by
+the reference itself (tests/golden/warp.npz), the integer-producing kernels with the oracle.
+Tolerance for fp32 convolutions: 2e-5 of the output's max magnitude (different summation
+order only; the MFMA path is an exact fmaf chain)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import dcvc_ref as R
+from tests.util import golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from vcm_ts_amd.engine import Engine
+
+    return Engine("cuda:0")
+
+
+def to_view(eng, name, x, cs=None):
+    N, C, H, W = x.shape
+    return eng.from_nchw(x.cuda(), eng.buf(name, N, H, W, C, cs=cs))
+
+
+def rel_err(got, want):
+    return ((got.cpu() - want).abs().max() / (want.abs().max() + 1e-20)).item()
+
+
+CONV_CASES = [
+    # cin segments, cout, ks, stride, H, W, ps, in_slope, out_slope, res, gate, res2
+    ((64,), 64, 3, 1, 40, 72, False, None, 0.01, True, False, False),
+    ((64,), 64, 3, 1, 33, 31, False, 0.01, None, True, False, True),
+    ((3, 64), 64, 3, 2, 32, 64, False, None, None, False, False, False),
+    ((8,), 32, 7, 1, 17, 45, False, None, 0.0, False, False, False),
+    ((32,), 64, 7, 1, 16, 40, False, None, 0.0, False, False, False),
+    ((16,), 2, 7, 1, 24, 33, False, None, None, True, False, False),
+    ((2,), 64, 3, 2, 64, 64, False, None, 0.01, False, False, False),
+    ((2,), 64, 1, 2, 64, 64, False, None, None, False, False, False),
+    ((64,), 256, 1, 1, 16, 24, True, None, 0.01, False, False, False),
+    ((96,), 256, 3, 1, 8, 12, True, None, None, False, False, False),
+    ((64,), 8, 1, 1, 20, 20, True, None, None, False, False, False),
+    ((192, 192, 96), 384, 3, 1, 4, 8, False, None, 0.2, False, False, False),
+    ((128, 64), 192, 3, 1, 17, 30, False, None, 0.2, False, False, False),
+    ((64, 64), 64, 1, 1, 16, 48, False, None, None, True, True, False),
+    ((144,), 576, 1, 1, 8, 8, True, None, 0.01, False, False, False),
+    ((64,), 3, 3, 1, 32, 96, False, None, "clamp01", False, False, False),
+    ((96,), 144, 3, 1, 16, 16, False, None, 0.01, False, False, False),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=[f"c{i}" for i in range(len(CONV_CASES))])
+def test_conv_matches_torch(eng, case):
+    segs, cout, ks, stride, H, W, ps, in_slope, out_slope, use_res, use_gate, use_res2 = case
+    g = torch.Generator().manual_seed(hash(case) % 1000)
+    N = 2
+    xs = [torch.randn(N, c, H, W, generator=g) for c in segs]
+    cin = sum(segs)
+    w = torch.randn(cout, cin, ks, ks, generator=g) / math.sqrt(cin * ks * ks)
+    b = torch.randn(cout, generator=g) * 0.1
+    x = torch.cat(xs, 1)
+    xin = x if in_slope is None else F.leaky_relu(x, in_slope)
+    want = F.conv2d(xin, w, b, stride=stride, padding=ks // 2)
+    if out_slope == "clamp01":
+        want = want.clamp(0, 1)
+    elif out_slope is not None:
+        want = F.leaky_relu(want, out_slope) if out_slope > 0 else F.relu(want)
+    if ps:
+        want = F.pixel_shuffle(want, 2)
+    res = gate = res2 = None
+    if use_res:
+        res = torch.randn(want.shape, generator=g)
+        r = res
+        if use_gate:
+            gate = torch.rand(N, want.shape[1], generator=g)
+            r = res * gate[:, :, None, None]
+        want = want + r
+    if use_res2:
+        res2 = torch.randn(want.shape, generator=g)
+        want = res2 + want
+    wp, bp = torch.nn.Parameter(w), torch.nn.Parameter(b)
+    pk = eng.pack(("t", case), wp, bp, segs, ps)
+    views = []
+    for i, (xx, c) in enumerate(zip(xs, segs)):
+        wide = eng.buf(f"t/in{i}", N, H, W, c + 8)  # odd channel stride + offset slice
+        views.append(eng.from_nchw(xx.cuda(), wide.slice(4, c)))
+    out = eng.buf("t/out", N, want.shape[2], want.shape[3], want.shape[1] + 4).slice(4, want.shape[1])
+    rv = to_view(eng, "t/res", res) if res is not None else None
+    r2 = to_view(eng, "t/res2", res2) if res2 is not None else None
+    gt = gate.cuda().contiguous() if gate is not None else None
+    eng.conv(pk, views, out, stride=stride, in_slope=in_slope, out_slope=out_slope, res=rv, gate=gt, res2=r2)
+    got = eng.to_nchw(out)
+    assert rel_err(got, want) < 2e-5
+
+
+def test_conv_rejects_bad_arguments(eng):
+    from vcm_ts_amd import lib
+
+    a = lib.ConvArgs()
+    assert eng.L.dcvc_conv2d(a, None) == -1  # nseg = 0
+    w = torch.nn.Parameter(torch.zeros(4, 4, 5, 5))
+    with pytest.raises(lib.KernelError):
+        eng.pack(("bad",), w, None, (4,), False)  # 5x5 unsupported
+
+
+def test_warp_and_resamplers_match_reference_fixtures(eng):
+    fx = golden("warp")
+    for k in range(int(fx["n_warp"])):
+        im, fl = torch.from_numpy(fx[f"warp{k}_im"]), torch.from_numpy(fx[f"warp{k}_flow"])
+        N, C, H, W = im.shape
+        out = eng.warp(to_view(eng, "w/im", im), to_view(eng, "w/fl", fl), eng.buf("w/out", N, H, W, C))
+        got = eng.to_nchw(out).cpu().numpy()
+        # positions are rebuilt with the reference's own fp32 arithmetic: tight even at W=1920
+        np.testing.assert_allclose(got, fx[f"warp{k}_out"], rtol=0, atol=3e-6 * np.abs(fx[f"warp{k}_im"]).max())
+    x = torch.from_numpy(fx["resamp_in"])
+    N, C, H, W = x.shape
+    up = eng.up2(to_view(eng, "r/in", x), eng.buf("r/up", N, 2 * H, 2 * W, C))
+    np.testing.assert_allclose(eng.to_nchw(up).cpu().numpy(), fx["resamp_up"], rtol=1e-6, atol=1e-7)
+    dn = eng.down2(to_view(eng, "r/in", x), eng.buf("r/dn", N, H // 2, W // 2, C))
+    np.testing.assert_allclose(eng.to_nchw(dn).cpu().numpy(), fx["resamp_down"], rtol=1e-6, atol=1e-7)
+    ap = eng.down2(to_view(eng, "r/in", x), eng.buf("r/ap", N, H // 2, W // 2, C), avgpool_order=True)
+    np.testing.assert_allclose(eng.to_nchw(ap).cpu().numpy(), F.avg_pool2d(x, 2, 2).numpy(), rtol=1e-6, atol=1e-7)
+    mp = eng.maxpool2(to_view(eng, "r/in", x), eng.buf("r/mp", N, H // 2, W // 2, C))
+    np.testing.assert_array_equal(eng.to_nchw(mp).cpu().numpy(), F.max_pool2d(x, 2).numpy())
+
+
+def test_warp_vector_path_and_border(eng):
+    g = torch.Generator().manual_seed(1)
+    im = torch.randn(1, 64, 24, 40, generator=g)
+    fl = torch.randn(1, 2, 24, 40, generator=g) * 30  # mostly out of the picture -> border clamp
+    want = R.warp(im, fl)
+    out = eng.warp(to_view(eng, "wv/im", im), to_view(eng, "wv/fl", fl), eng.buf("wv/out", 1, 24, 40, 64))
+    assert rel_err(eng.to_nchw(out), want) < 3e-6
+
+
+def test_layout_round_trip(eng):
+    x = torch.randn(2, 67, 19, 23)
+    v = to_view(eng, "l/x", x, cs=72)
+    np.testing.assert_array_equal(eng.to_nchw(v).cpu().numpy(), x.numpy())
+    np.testing.assert_array_equal(v.nchw().cpu().numpy(), x.numpy())  # zero-copy logical NCHW view
+    from vcm_ts_amd.engine import View
+
+    al = View.alias(v.nchw())
+    assert al is not None and al.ptr == v.ptr and al.cs == 72
+
+
+def test_se_gate(eng):
+    g = torch.Generator().manual_seed(2)
+    t = torch.randn(2, 32, 48, 80, generator=g)
+    w1, w2 = torch.randn(2, 32, generator=g), torch.randn(32, 2, generator=g)
+    want = torch.sigmoid(F.linear(F.relu(F.linear(t.mean(dim=(-1, -2)), w1)), w2))
+    gate = eng.se_gate("se/t", to_view(eng, "se/in", t), w1.cuda(), w2.cuda())
+    torch.testing.assert_close(gate.cpu().reshape(2, 32), want, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("dist,C", [("laplace", 64), ("gaussian", 192)])
+def test_dual_prior_matches_oracle(eng, dist, C):
+    """Encoder kernels (estimate + symbol planes) against oracle.dual_prior with the spatial
+    prior replaced by a fixed random tensor, then the decoder kernels fed the same symbols."""
+    g = torch.Generator().manual_seed(3)
+    N, H, W = 2, 10, 14
+    y = torch.randn(N, C, H, W, generator=g) * 4
+    fusion = torch.randn(N, 3 * C, H, W, generator=g)
+    fusion[:, C : 2 * C] = fusion[:, C : 2 * C].abs() * 2  # scales (some below the table minimum)
+    spatial = torch.randn(N, 2 * C, H, W, generator=g)
+    spatial[:, : C // 2] = spatial[:, : C // 2].abs()
+    spatial[:, C : C + C // 2] = spatial[:, C : C + C // 2].abs()
+    qb, qs = torch.rand(C, generator=g) + 0.3, torch.tensor([1.2, 0.7])
+
+    class FixedPrior(dict):
+        pass
+
+    # oracle with the spatial prior conv stack monkey-patched to return `spatial`
+    orig = R.three_convs
+    R.three_convs = lambda w, name, x, slope=0.2: spatial
+    try:
+        qs_, sc_, mu_ = fusion.chunk(3, 1)
+        o = R.dual_prior({}, "x", y, mu_, sc_, qs_)
+    finally:
+        R.three_convs = orig
+    curr_q = (qb.clamp_min(0.5)[None, :, None, None] * qs[:, None, None, None])
+    want_out = o["y_hat"] * curr_q
+
+    yv, fv, sv = to_view(eng, "dp/y", y), to_view(eng, "dp/f", fusion), to_view(eng, "dp/s", spatial)
+    params = eng.buf("dp/params", N, H, W, 4 * C)
+    n = N * H * W * C
+    y_hat, y_q, sh = eng.fbuf("dp/yh", n), eng.fbuf("dp/yq", n), eng.fbuf("dp/sh", n)
+    sym = [eng.ibuf(f"dp/sym{k}", n // 2) for k in (0, 1)]
+    idx = [eng.ibuf(f"dp/idx{k}", n // 2) for k in (0, 1)]
+    out = eng.buf("dp/out", N, H, W, C)
+    common = dict(y=yv, fusion=fv, params=params, y_hat=y_hat, y_q=y_q, scales_hat=sh, distribution=dist)
+    eng.dual_prior("enc", 0, sym=sym[0], idx=idx[0], **common)
+    want_params = torch.cat((o["q_w0"] * 0, ) , 1)  # placeholder to keep shapes obvious
+    eng.dual_prior("enc", 1, spatial=sv, sym=sym[1], idx=idx[1], out=out, q_basic=qb.cuda(), q_scale=qs.cuda(), **common)
+    nhwc = lambda t: t.permute(0, 2, 3, 1).reshape(-1)
+    torch.testing.assert_close(y_q.cpu(), nhwc(o["y_q"]), rtol=0, atol=0)
+    torch.testing.assert_close(sh.cpu(), nhwc(o["scales_hat"]), rtol=0, atol=0)
+    torch.testing.assert_close(eng.to_nchw(out).cpu(), want_out, rtol=1e-6, atol=1e-6)
+    for k, (qw, sw) in enumerate(((o["q_w0"], o["s_w0"]), (o["q_w1"], o["s_w1"]))):
+        np.testing.assert_array_equal(sym[k].cpu().numpy().reshape(N, C // 2, H, W), qw.numpy().astype(np.int32))
+        want_idx = R.scale_indexes(sw, dist).numpy()
+        got_idx = idx[k].cpu().numpy().reshape(N, C // 2, H, W)
+        # the float->int hinge: identical except where logf lands within 1 ulp of a bin edge
+        assert (got_idx != want_idx).mean() < 1e-3
+        assert np.abs(got_idx - want_idx).max() <= 1
+    # params buffer after step 0 = [y_hat_0_0 | y_hat_1_1 | means | scales | q_step]
+    # decoder: same indexes, then apply the encoder's symbols -> identical y_hat, bit for bit
+    y_hat2 = eng.fbuf("dp/yh2", n)
+    out2 = eng.buf("dp/out2", N, H, W, C)
+    params2 = eng.buf("dp/params2", N, H, W, 4 * C)
+    idx2 = eng.ibuf("dp/idx_d", n // 2)
+    dcommon = dict(fusion=fv, params=params2, y_hat=y_hat2, distribution=dist)
+    eng.dual_prior("dec_index", 0, idx=idx2, **dcommon)
+    np.testing.assert_array_equal(idx2.cpu().numpy(), idx[0].cpu().numpy())
+    eng.dual_prior("dec_apply", 0, sym=sym[0], **dcommon)
+    np.testing.assert_array_equal(params2.base.cpu().numpy(), params.base.cpu().numpy())
+    eng.dual_prior("dec_index", 1, spatial=sv, idx=idx2, **dcommon)
+    np.testing.assert_array_equal(idx2.cpu().numpy(), idx[1].cpu().numpy())
+    eng.dual_prior("dec_apply", 1, spatial=sv, sym=sym[1], out=out2, q_basic=qb.cuda(), q_scale=qs.cuda(), **dcommon)
+    np.testing.assert_array_equal(out2.base.cpu().numpy(), out.base.cpu().numpy())
+
+
+def test_bit_estimates_match_oracle(eng):
+    g = torch.Generator().manual_seed(4)
+    yq = torch.round(torch.randn(2, 5000, generator=g) * 3)
+    sc = torch.rand(2, 5000, generator=g) * 4 - 0.2
+    for gaussian, fn in ((False, R.laplace_bits), (True, R.gaussian_bits)):
+        want = fn(yq, sc).sum(dim=1)
+        got = eng.scale_bits(yq.cuda().contiguous(), sc.cuda().contiguous(), 2, 5000, gaussian=gaussian)
+        torch.testing.assert_close(got.cpu(), want, rtol=2e-5, atol=1e-3)
+    from tests.util import oracle_weights
+    from vcm_ts_amd import entropy as E
+
+    w = oracle_weights("dmc")
+    z = torch.round(torch.randn(2, 64, 6, 9, generator=g) * 2)
+    want = R.z_bits(w, "bit_estimator_z", z).sum(dim=(1, 2, 3))
+    blk = E.factorized_param_block(E.factorized_params(w, "bit_estimator_z")).cuda()
+    got = eng.factorized_bits(to_view(eng, "fb/z", z), blk)
+    torch.testing.assert_close(got.cpu(), want, rtol=2e-5, atol=1e-3)
+    a, b = torch.rand(2, 3, 20, 30, generator=g), torch.rand(2, 3, 20, 30, generator=g)
+    got = eng.sq_err(to_view(eng, "se/a", a, cs=8), to_view(eng, "se/b", b))
+    torch.testing.assert_close(got.cpu(), ((a - b) ** 2).sum(dim=(1, 2, 3)), rtol=1e-5, atol=1e-5)
+
+
+def test_round_symbols_half_to_even(eng):
+    z = torch.tensor([0.5, 1.5, 2.5, -0.5, -1.5, 3.49999, -7.5, 0.0]).reshape(1, 8, 1, 1)
+    zh = eng.buf("rs/zh", 1, 1, 1, 8)
+    sym = eng.ibuf("rs/sym", 8)
+    eng.round_symbols(to_view(eng, "rs/z", z), zh, sym)
+    np.testing.assert_array_equal(sym.cpu().numpy(), torch.round(z).reshape(-1).int().numpy())
+    back = eng.symbols_to_nhwc(sym, eng.buf("rs/back", 1, 1, 1, 8))
+    np.testing.assert_array_equal(eng.to_nchw(back).cpu().numpy(), torch.round(z).numpy())

@@ -81,6 +81,7 @@ class Engine:
         self.bufs = {}
         self.packs = {}
         self.calls = 0
+        self.profile = None  # set to {} to time every conv launch with HIP events (bench.py)
 
     # ------------------------------------------------------------------ memory
     def stream(self):
@@ -203,9 +204,22 @@ class Engine:
         if res2 is not None:
             assert (res2.N, res2.H, res2.W, res2.C) == (out.N, out.H, out.W, out.C)
             a.res2, a.res2_cs = res2.ptr, res2.cs
-        lib.check(self.L.dcvc_conv2d(C.byref(a), self.stream()), "conv2d")
+        if self.profile is None:
+            lib.check(self.L.dcvc_conv2d(C.byref(a), self.stream()), "conv2d")
+        else:  # events go on the stream the kernel is launched on (torch's current stream)
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
+            lib.check(self.L.dcvc_conv2d(C.byref(a), self.stream()), "conv2d")
+            ev1.record()
+            flops = 2.0 * s0.N * Ho * Wo * pk.Cout * sum(pk.seg_C) * pk.ks * pk.ks  # algorithmic, unpadded
+            self.profile.setdefault(f"conv{pk.ks}x{pk.ks}s{stride}", []).append((ev0, ev1, flops))
         self.calls += 1
         return out
+
+    def collect_profile(self):
+        torch.cuda.synchronize(self.device)
+        return {k: {"flops": sum(f for _, _, f in v), "ms": sum(a.elapsed_time(b) for a, b, _ in v), "launches": len(v)}
+                for k, v in (self.profile or {}).items()}
 
     # ------------------------------------------------------------------ resampling
     def warp(self, src: View, flow: View, out: View):

@@ -1,0 +1,70 @@
+"""GOP encode loop over the two codecs: the hot loop of the reference's
+``video_coder.run_dcvc`` (/root/reference/video_coder.py:80-155) with the redundant decode
+pass removed.
+
+The reference calls ``encode_decode`` per frame, i.e. compress + file write + file read +
+decompress, because its ``compress`` hides the encoder-side DPB behind a misspelt key
+(video_model.py:344).  Here ``compress`` returns the DPB it already computed (clamped like the
+decoder's, so both sides hold bit-identical references), and a GOP is a strict chain of
+compress calls.  GOPs are independent (each starts from an I picture and an empty DPB), so
+several GOPs shard across GPUs / processes with no exchange (``shard_gops``).
+"""
+from __future__ import annotations
+
+import torch
+
+from . import stream as S
+
+
+def pad_frame(x: torch.Tensor):
+    """Pad right/bottom to multiples of 64 with zeros (video_coder.py:111-117)."""
+    h, w = x.shape[-2:]
+    l, r, t, b = S.get_padding_size(h, w)
+    return torch.nn.functional.pad(x, (l, r, t, b), mode="constant", value=0)
+
+
+def shard_gops(n_gops: int, rank: int, world: int):
+    """GOP g -> rank g mod world: no data-path collective is needed."""
+    return [g for g in range(n_gops) if g % world == rank]
+
+
+class GopEncoder:
+    def __init__(self, i_frame_net, p_frame_net, gop_size=32):
+        self.i_net, self.p_net, self.gop = i_frame_net, p_frame_net, int(gop_size)
+        self.i_net.update()
+        self.p_net.update()
+
+    def encode_gop(self, frames, q_i, q_mv_y, q_y, sink=None):
+        """frames: iterable of padded (1, 3, H, W) device tensors, the first coded as an I
+        picture.  Returns (list of payload bytes with their headers' q indexes, total bits of
+        the payloads + headers).  `sink(kind, index, header_fields, payload)` may persist them."""
+        q_i, qi_idx = S.get_rounded_q(q_i)
+        q_mv_y, qmv_idx = S.get_rounded_q(q_mv_y)
+        q_y, qy_idx = S.get_rounded_q(q_y)
+        out, bits, dpb = [], 0, None
+        for t, x in enumerate(frames):
+            if t % self.gop == 0:
+                r = self.i_net.compress(x, q_i)
+                dpb = {"ref_frame": r["x_hat"], "ref_feature": None, "ref_y": None, "ref_mv_y": None}
+                out.append(("I", (qi_idx,), r["bit_stream"]))
+                bits += (len(r["bit_stream"]) + 14) * 8  # >IIHI header
+            else:
+                r = self.p_net.compress(x, dpb, q_mv_y, q_y)
+                dpb = r["dpb"]
+                out.append(("P", (qmv_idx, qy_idx), r["bit_stream"]))
+                bits += (len(r["bit_stream"]) + 8) * 8  # >HHI header
+            if sink is not None:
+                sink(*out[-1], t)
+        return out, bits, dpb
+
+    def decode_gop(self, coded, height, width):
+        """Inverse of encode_gop (the reference decoder path): returns the list of x_hat."""
+        recs, dpb = [], None
+        for kind, q, payload in coded:
+            if kind == "I":
+                x_hat = self.i_net.decompress(payload, height, width, q[0] / 100)["x_hat"]
+                dpb = {"ref_frame": x_hat, "ref_feature": None, "ref_y": None, "ref_mv_y": None}
+            else:
+                dpb = self.p_net.decompress(dpb, payload, height, width, q[0] / 100, q[1] / 100)["dpb"]
+            recs.append(dpb["ref_frame"].clone())
+        return recs
