@@ -110,24 +110,19 @@ def main():
     seq = [pad_frame(f) for f in synth_sequence(dev, args.gop, args.height, args.width, seed=rank)]
     q_i, q_mv, q_y = 1.0, 1.0, 1.0
 
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
+    from vcm_ts_amd.pipeline import timed_region
 
     bits = 0
     for _ in range(args.warmup):
         _, bits, _ = enc.encode_gop(seq, q_i, q_mv, q_y)
-    barrier()
-    t0 = time.time()
-    for _ in range(args.steps):
-        _, bits, _ = enc.encode_gop(seq, q_i, q_mv, q_y)
-    barrier()
-    dt = time.time() - t0
-    if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = t.item()
+
+    def work():
+        b = 0
+        for _ in range(args.steps):
+            _, b, _ = enc.encode_gop(seq, q_i, q_mv, q_y)
+        return b
+
+    dt, bits = timed_region(work, dev)
     frames_total = args.gop * args.steps * world
     fps = frames_total / dt
 

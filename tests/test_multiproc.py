@@ -1,0 +1,94 @@
+"""N > 1 orchestration on CPU: world_size-2 gloo.  GOPs are independent units, so sharding
+needs no data-path collective; what must hold is that the shards partition the work, that a
+rank's output does not depend on the world size, and that the timing reduction used by
+bench.py (barrier, MAX over ranks) behaves.  The per-GOP work here is the host half of the
+product path (libdcvc_rans entropy coding of seeded symbol planes) -- the device half needs a
+GPU and is covered by the -m gpu tests."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from tests.util import ROOT, golden
+from vcm_ts_amd.pipeline import shard_gops, timed_region
+
+
+def _encode_fake_gop(g, tables):
+    from vcm_ts_amd import entropy as E
+
+    cdf, ln, off = tables
+    rng = np.random.default_rng(1000 + g)
+    enc = E.BufferedRansEncoder()
+    out = []
+    for _ in range(4):  # 4 pictures per GOP
+        enc.reset()
+        for n in (256, 2048, 2048):
+            enc.encode_with_indexes(np.rint(rng.laplace(0, 2, n)).astype(np.int32), rng.integers(0, 256, n).astype(np.int32), cdf, ln, off)
+        out.append(enc.flush())
+    return out
+
+
+def _worker(rank, world, port, n_gops, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    t = golden("tables")
+    tables = (t["dmc_scale_cdf"], t["dmc_scale_len"], t["dmc_scale_off"])
+    mine = shard_gops(n_gops, rank, world)
+    dt, coded = timed_region(lambda: {g: _encode_fake_gop(g, tables) for g in mine})
+    gathered = [None] * world
+    dist.all_gather_object(gathered, (mine, coded, dt))
+    if rank == 0:
+        q.put(gathered)
+    dist.destroy_process_group()
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def test_shards_partition_the_gops():
+    for n, w in ((8, 2), (7, 3), (1, 4), (16, 8), (0, 2)):
+        shards = [shard_gops(n, r, w) for r in range(w)]
+        flat = sorted(g for s in shards for g in s)
+        assert flat == list(range(n))
+        assert max(len(s) for s in shards) - min(len(s) for s in shards) <= 1
+
+
+@pytest.mark.timeout(120)
+def test_two_rank_gloo_run_matches_single_process():
+    n_gops, world = 5, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_gops, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    gathered = q.get(timeout=100)
+    for p in procs:
+        p.join(timeout=30)
+        assert p.exitcode == 0
+    t = golden("tables")
+    tables = (t["dmc_scale_cdf"], t["dmc_scale_len"], t["dmc_scale_off"])
+    seen = {}
+    times = set()
+    for mine, coded, dt in gathered:
+        assert sorted(coded) == mine
+        seen.update(coded)
+        times.add(dt)
+    assert sorted(seen) == list(range(n_gops))
+    assert len(times) == 1  # every rank reports the same (max-reduced) time
+    for g in range(n_gops):  # bytes do not depend on how the GOPs were sharded
+        assert seen[g] == _encode_fake_gop(g, tables)
+
+
+def test_timed_region_single_process():
+    dt, r = timed_region(lambda: 41 + 1)
+    assert r == 42 and dt >= 0

@@ -28,6 +28,33 @@ def shard_gops(n_gops: int, rank: int, world: int):
     return [g for g in range(n_gops) if g % world == rank]
 
 
+def timed_region(fn, device=None):
+    """Run fn() between barriers and return the slowest rank's wall time in seconds (what
+    bench.py reports): barrier + device sync on both sides, MAX over ranks."""
+    import time
+
+    import torch.distributed as dist
+
+    multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+    def fence():
+        if multi:
+            dist.barrier()
+        if device is not None and torch.device(device).type == "cuda":
+            torch.cuda.synchronize(device)
+
+    fence()
+    t0 = time.time()
+    result = fn()
+    fence()
+    dt = time.time() - t0
+    if multi:
+        t = torch.tensor([dt], dtype=torch.float64, device=device if device is not None else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt, result
+
+
 class GopEncoder:
     def __init__(self, i_frame_net, p_frame_net, gop_size=32):
         self.i_net, self.p_net, self.gop = i_frame_net, p_frame_net, int(gop_size)
