@@ -1,0 +1,54 @@
+"""CPU emulation of the split-fp16 convolution (hi/lo fp16 operands, 3 products, fp32 accumulate)
+through the whole oracle network: how far do bpp / mse move from the exact-fp32 oracle?"""
+import os, sys
+import numpy as np, torch, torch.nn.functional as F
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import dcvc_ref as R
+from vcm_ts_amd.params import dmc_spec, intra_spec, seeded_state_dict
+from vcm_ts_amd.synthetic import frames
+
+def split(t, bits16="fp16"):
+    if bits16 == "fp16":
+        t = t.clamp(-65504, 65504)
+        hi = t.half().float()
+        lo = ((t - hi) * 2048.0).half().float()
+        return hi, lo, 1.0 / 2048.0
+    hi = t.bfloat16().float()
+    lo = (t - hi).bfloat16().float()
+    return hi, lo, 1.0
+
+MODE = "fp16"
+def conv_split(w, name, x, stride=1):
+    wt = w[name + ".weight"]; pad = wt.shape[-1] // 2
+    xh, xl, s = split(x, MODE); wh, wl, _ = split(wt, MODE)
+    main = F.conv2d(xh, wh, None, stride=stride, padding=pad)
+    cross = F.conv2d(xh, wl, None, stride=stride, padding=pad) + F.conv2d(xl, wh, None, stride=stride, padding=pad)
+    return main + cross * s + w[name + ".bias"][None, :, None, None]
+
+def run(h, w, nf, conv_fn):
+    orig = R.conv; R.conv = conv_fn
+    try:
+        wd, wi = seeded_state_dict(dmc_spec()), seeded_state_dict(intra_spec())
+        fr = frames(0, nf, h, w); xs = [torch.from_numpy(fr[t:t+1]) for t in range(nf)]
+        out = []
+        with torch.no_grad():
+            ri = R.intra_forward(wi, xs[0], 1.0); out.append((ri["bpp"].item(), ri["mse"].item()))
+            dpb = {"ref_frame": ri["x_hat"].clamp(0,1), "ref_feature": None, "ref_y": None, "ref_mv_y": None}
+            for t in range(1, nf):
+                r = R.dmc_forward_one_frame(wd, xs[t], dpb, 1.0, 1.0); dpb = r["dpb"]
+                dpb["ref_frame"] = dpb["ref_frame"].clamp(0, 1)
+                out.append((r["bpp"].item(), r["mse"].item()))
+        return out
+    finally:
+        R.conv = orig
+
+if __name__ == "__main__":
+    h, w, nf = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
+    torch.set_num_threads(8)
+    base = run(h, w, nf, R.conv)
+    for MODE in ("fp16", "bf16"):
+        got = run(h, w, nf, conv_split)
+        print(MODE)
+        for t, (a, b) in enumerate(zip(base, got)):
+            print(f"  frame {t}: bpp {a[0]:.6f} vs {b[0]:.6f} rel {abs(a[0]-b[0])/a[0]:.2e} | mse {a[1]:.6f} vs {b[1]:.6f} rel {abs(a[1]-b[1])/a[1]:.2e} dPSNR {abs(10*np.log10(a[1]/b[1])):.2e} dB")

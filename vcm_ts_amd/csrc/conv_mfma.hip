@@ -89,66 +89,119 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_f32(const ConvK a) {
     const int a_base = ((wave * RPW * S) * PW + (lane & 31) * S) * LDK + (lane >> 5) * 4;
     const int b_base = ((lane >> 5) * BN + (lane & 31)) * 4;
 
-    int cg = 0;
-    for (int s = 0; s < a.nseg; ++s) {
-        const int C = a.seg_C[s], cs = a.seg_cs[s];
-        const float *sp = a.seg_ptr[s] + (size_t)img * a.Hin * a.Win * cs;
-        for (int c0 = 0; c0 < C; c0 += KC, ++cg) {
-            __syncthreads();
-            for (int i = tid; i < PH * PW * 4; i += 256) {
-                const int p = i >> 2, q = i & 3;
-                const int py = p / PW, px = p - py * PW;
-                const int gy = y0 * S - PAD + py, gx = x0 * S - PAD + px;
-                const int c = c0 + q * 4;
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (gy >= 0 && gy < a.Hin && gx >= 0 && gx < a.Win && c < C) {
-                    v = *(const f32x4 *)(sp + ((size_t)gy * a.Win + gx) * cs + c);
-                    if (c + 3 >= C) {
-                        if (c + 1 >= C) v[1] = 0.f;
-                        if (c + 2 >= C) v[2] = 0.f;
-                        v[3] = 0.f;
-                    }
-                    if (a.in_act) {
-                        v[0] = act(v[0], a.in_slope);
-                        v[1] = act(v[1], a.in_slope);
-                        v[2] = act(v[2], a.in_slope);
-                        v[3] = act(v[3], a.in_slope);
-                    }
-                }
-                *(f32x4 *)&patch[p * LDK + q * 4] = v;
-            }
-            for (int st = 0; st < NST; ++st) {
-                if (st > 0) __syncthreads();
-                const float *wsrc = a.wpack + ((size_t)(cg * T + st * TPS) * 4) * a.Cout_pad * 4 + (size_t)n0 * 4;
-                for (int i = tid; i < TPS * 4 * BN; i += 256) {
-                    const int row = i / BN, col = i - row * BN;
-                    *(f32x4 *)&wl[i * 4] = *(const f32x4 *)(wsrc + ((size_t)row * a.Cout_pad + col) * 4);
-                }
-                __syncthreads();
-                const int a_st = (TPS == T) ? 0 : st * PW * LDK;  // staged by filter row
-#pragma unroll
-                for (int tt = 0; tt < TPS; ++tt) {
-                    const int ky = (TPS == T) ? tt / KS : 0, kx = (TPS == T) ? tt % KS : tt;
-#pragma unroll
-                    for (int k2 = 0; k2 < 2; ++k2) {
-                        f32x4 af[RPW], bf[NT];
-#pragma unroll
-                        for (int m = 0; m < RPW; ++m)
-                            af[m] = *(const f32x4 *)&patch[a_base + a_st + ((m * S + ky) * PW + kx) * LDK + k2 * 8];
-#pragma unroll
-                        for (int n = 0; n < NT; ++n)
-                            bf[n] = *(const f32x4 *)&wl[b_base + ((tt * 4 + k2 * 2) * BN + n * 32) * 4];
-#pragma unroll
-                        for (int j = 0; j < 4; ++j)
-#pragma unroll
-                            for (int m = 0; m < RPW; ++m)
-#pragma unroll
-                                for (int n = 0; n < NT; ++n)
-                                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[m][j], bf[n][j], acc[m][n], 0, 0, 0);
-                    }
-                }
+    // ---- software-pipelined main loop.  A "step" is (16-channel chunk, tap stage); while the
+    // MFMAs of step k run, the global loads of step k+1 are already in flight into registers
+    // (rp: input patch, only when the chunk changes; rw: filter slab) and are written to LDS
+    // after the barrier that ends step k.
+    constexpr int NP = (PH * PW * 4 + 255) / 256, NW = (TPS * 4 * BN + 255) / 256;
+    f32x4 rp[NP], rw[NW];
+    struct Cursor {
+        int s, c0, cg, st;
+    };
+    auto advance = [&](Cursor &k) {
+        if (++k.st == NST) {
+            k.st = 0;
+            ++k.cg;
+            k.c0 += KC;
+            if (k.c0 >= a.seg_C[k.s]) {
+                ++k.s;
+                k.c0 = 0;
             }
         }
+    };
+    auto load_patch = [&](const Cursor &k) {
+        const int C = a.seg_C[k.s], cs = a.seg_cs[k.s];
+        const float *sp = a.seg_ptr[k.s] + (size_t)img * a.Hin * a.Win * cs;
+#pragma unroll
+        for (int u = 0; u < NP; ++u) {
+            const int i = tid + u * 256;
+            const int p = i >> 2, q = i & 3;
+            const int py = p / PW, px = p - py * PW;
+            const int gy = y0 * S - PAD + py, gx = x0 * S - PAD + px;
+            const int c = k.c0 + q * 4;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (i < PH * PW * 4 && gy >= 0 && gy < a.Hin && gx >= 0 && gx < a.Win && c < C)
+                v = *(const f32x4 *)(sp + ((size_t)gy * a.Win + gx) * cs + c);
+            rp[u] = v;
+        }
+    };
+    auto store_patch = [&](const Cursor &k) {
+        const int C = a.seg_C[k.s];
+#pragma unroll
+        for (int u = 0; u < NP; ++u) {
+            const int i = tid + u * 256;
+            if (i < PH * PW * 4) {
+                const int c = k.c0 + (i & 3) * 4;
+                f32x4 v = rp[u];
+                if (c + 3 >= C) {  // channels past the segment's end read as zero
+                    if (c + 1 >= C) v[1] = 0.f;
+                    if (c + 2 >= C) v[2] = 0.f;
+                    v[3] = 0.f;
+                }
+                if (a.in_act) {
+                    v[0] = act(v[0], a.in_slope);
+                    v[1] = act(v[1], a.in_slope);
+                    v[2] = act(v[2], a.in_slope);
+                    v[3] = act(v[3], a.in_slope);
+                }
+                *(f32x4 *)&patch[(i >> 2) * LDK + (i & 3) * 4] = v;
+            }
+        }
+    };
+    auto load_w = [&](const Cursor &k) {
+        const float *wsrc = a.wpack + ((size_t)(k.cg * T + k.st * TPS) * 4) * a.Cout_pad * 4 + (size_t)n0 * 4;
+#pragma unroll
+        for (int u = 0; u < NW; ++u) {
+            const int i = tid + u * 256;
+            const int row = i / BN, col = i - row * BN;
+            if (i < TPS * 4 * BN) rw[u] = *(const f32x4 *)(wsrc + ((size_t)row * a.Cout_pad + col) * 4);
+        }
+    };
+    auto store_w = [&]() {
+#pragma unroll
+        for (int u = 0; u < NW; ++u) {
+            const int i = tid + u * 256;
+            if (i < TPS * 4 * BN) *(f32x4 *)&wl[i * 4] = rw[u];
+        }
+    };
+
+    Cursor cur = {0, 0, 0, 0};
+    load_patch(cur);
+    load_w(cur);
+    while (cur.s < a.nseg) {
+        __syncthreads();  // every wave is done reading the previous step's LDS
+        if (cur.st == 0) store_patch(cur);
+        store_w();
+        __syncthreads();
+        Cursor nxt = cur;
+        advance(nxt);
+        if (nxt.s < a.nseg) {
+            if (nxt.st == 0) load_patch(nxt);
+            load_w(nxt);
+        }
+        const int a_st = (TPS == T) ? 0 : cur.st * PW * LDK;  // staged by filter row
+#pragma unroll
+        for (int tt = 0; tt < TPS; ++tt) {
+            const int ky = (TPS == T) ? tt / KS : 0, kx = (TPS == T) ? tt % KS : tt;
+#pragma unroll
+            for (int k2 = 0; k2 < 2; ++k2) {
+                f32x4 af[RPW], bf[NT];
+#pragma unroll
+                for (int m = 0; m < RPW; ++m)
+                    af[m] = *(const f32x4 *)&patch[a_base + a_st + ((m * S + ky) * PW + kx) * LDK + k2 * 8];
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+                    bf[n] = *(const f32x4 *)&wl[b_base + ((tt * 4 + k2 * 2) * BN + n * 32) * 4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int m = 0; m < RPW; ++m)
+#pragma unroll
+                        for (int n = 0; n < NT; ++n)
+                            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[m][j], bf[n][j], acc[m][n], 0, 0, 0);
+            }
+        }
+        cur = nxt;
     }
 
     // ---- epilogue: bias, activation, (gated) residual, NHWC or pixel-shuffled store

@@ -82,6 +82,7 @@ class Engine:
         self.packs = {}
         self.calls = 0
         self.profile = None  # set to {} to time every conv launch with HIP events (bench.py)
+        self.profile_detail = None
 
     # ------------------------------------------------------------------ memory
     def stream(self):
@@ -213,6 +214,9 @@ class Engine:
             ev1.record()
             flops = 2.0 * s0.N * Ho * Wo * pk.Cout * sum(pk.seg_C) * pk.ks * pk.ks  # algorithmic, unpadded
             self.profile.setdefault(f"conv{pk.ks}x{pk.ks}s{stride}", []).append((ev0, ev1, flops))
+            if self.profile_detail is not None:
+                self.profile_detail.append((ev0, ev1, flops, f"k{pk.ks}s{stride} {pk.seg_C}->{pk.Cout}{'ps' if pk.ps else ''} "
+                                                             f"{s0.H}x{s0.W}"))
         self.calls += 1
         return out
 
