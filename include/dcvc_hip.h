@@ -48,6 +48,14 @@ extern "C" {
 
 #define DCVC_MAX_SEG 3
 
+/* Arithmetic of dcvc_conv2d.  FP32: v_mfma_f32_32x32x2_f32, bitwise an fp32 fmaf chain ("parity
+ * mode").  FP16X3: every fp32 operand split into fp16 hi + lo, three v_mfma_f32_32x32x16_f16 per
+ * product with fp32 accumulation; operand representation error <= max(2^-22 |v|, ~4e-9),
+ * dropped term <= 2^-22 |x w|; |activation| must stay below 8188 and |weight| below 1023
+ * (clamped).  Weights must be packed for the precision they are used with. */
+#define DCVC_PREC_FP32 0
+#define DCVC_PREC_FP16X3 1
+
 /* One input segment of a convolution: the kernel walks segments in order, which is the
  * channel order of the torch.cat the reference would have materialised. */
 typedef struct {
@@ -81,6 +89,7 @@ typedef struct {
     const float *res_gate;/* optional (N, Cfinal) per-sample per-channel factor on res (SE gate) */
     const float *res2;    /* optional second residual, added last: out = res2 + (act(conv) + res) */
     int32_t res2_cs;
+    int32_t precision;    /* DCVC_PREC_* ; must match the packing of wpack */
 } dcvc_conv_args;
 
 /* Number of floats dcvc_conv_pack_weights writes to wpack for this geometry, and the padded
@@ -90,7 +99,8 @@ int64_t dcvc_conv_pack_size(int32_t Cout, int32_t ks, int32_t nseg, const int32_
 /* HOST function.  w: (Cout, sum(seg_C), ks, ks) fp32 as nn.Conv2d stores it; b: (Cout) or
  * NULL.  Writes host buffers wpack / bpack which the caller uploads once. */
 int dcvc_conv_pack_weights(const float *w, const float *b, int32_t Cout, int32_t ks, int32_t nseg,
-                           const int32_t *seg_C, int32_t pixel_shuffle, float *wpack, float *bpack);
+                           const int32_t *seg_C, int32_t pixel_shuffle, int32_t precision, float *wpack,
+                           float *bpack);
 
 int dcvc_conv2d(const dcvc_conv_args *a, void *stream);
 

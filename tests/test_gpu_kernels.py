@@ -56,6 +56,43 @@ CONV_CASES = [
 ]
 
 
+@pytest.fixture(scope="module")
+def eng_split():
+    from vcm_ts_amd.engine import Engine
+
+    return Engine("cuda:0", precision="fp16x3")
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=[f"c{i}" for i in range(len(CONV_CASES))])
+def test_split_fp16_conv_matches_fp64(eng_split, case):
+    """fast mode (fp16 hi/lo operands, 3 MFMAs, fp32 accumulate) against an fp64 reference:
+    error bound 3e-6 of the output scale (fp32 mode: ~2e-7), incl. operands far below fp16's
+    normal range (handled by the pre-scales + MFMA subnormal support)."""
+    segs, cout, ks, stride, H, W, ps, in_slope, out_slope, use_res, use_gate, use_res2 = case
+    if use_res or use_res2:
+        pytest.skip("epilogue identical to the fp32 kernel; covered there")
+    eng = eng_split
+    g = torch.Generator().manual_seed(hash(case) % 1000 + 7)
+    N = 1
+    cin = sum(segs)
+    mag = torch.tensor([1e-4, 1.0, 30.0])[torch.randint(0, 3, (N, cin, 1, 1), generator=g)]
+    x = torch.randn(N, cin, H, W, generator=g) * mag
+    w = torch.randn(cout, cin, ks, ks, generator=g) / math.sqrt(cin * ks * ks)
+    b = torch.randn(cout, generator=g) * 0.1
+    xin = x.double() if in_slope is None else F.leaky_relu(x.double(), in_slope)
+    want = F.conv2d(xin, w.double(), b.double(), stride=stride, padding=ks // 2)
+    scale = F.conv2d(xin.abs(), w.double().abs(), None, stride=stride, padding=ks // 2).max().item()
+    pk = eng.pack(("t64", case), torch.nn.Parameter(w), torch.nn.Parameter(b), segs, False)
+    views, c0 = [], 0
+    for i, c in enumerate(segs):
+        views.append(to_view(eng, f"t64/in{i}", x[:, c0 : c0 + c]))
+        c0 += c
+    out = eng.buf("t64/out", N, want.shape[2], want.shape[3], cout)
+    eng.conv(pk, views, out, stride=stride, in_slope=in_slope)
+    got = eng.to_nchw(out).cpu().double()
+    assert (got - want).abs().max().item() < 3e-6 * scale
+
+
 @pytest.mark.parametrize("case", CONV_CASES, ids=[f"c{i}" for i in range(len(CONV_CASES))])
 def test_conv_matches_torch(eng, case):
     segs, cout, ks, stride, H, W, ps, in_slope, out_slope, use_res, use_gate, use_res2 = case

@@ -25,7 +25,8 @@ def main():
     w = int(sys.argv[2]) if len(sys.argv) > 2 else h
     dev = torch.device("cuda:0")
     wd, wi = seeded_state_dict(dmc_spec()), seeded_state_dict(intra_spec())
-    d, i = DMC().to(dev).eval(), IntraNoAR().to(dev).eval()
+    prec = sys.argv[3] if len(sys.argv) > 3 else "fp32"
+    d, i = DMC(precision=prec).to(dev).eval(), IntraNoAR(precision=prec).to(dev).eval()
     fr = frames(0, 3, h, w)
     xs = [torch.from_numpy(fr[t : t + 1]) for t in range(3)]
     with torch.no_grad():

@@ -8,7 +8,8 @@ from vcm_ts_amd.intra import IntraNoAR
 from vcm_ts_amd.pipeline import pad_frame
 from bench import synth_sequence
 dev = torch.device("cuda:0")
-i_net, p_net = IntraNoAR().to(dev).eval(), DMC().to(dev).eval()
+prec = sys.argv[2] if len(sys.argv) > 2 else "fp32"
+i_net, p_net = IntraNoAR(precision=prec).to(dev).eval(), DMC(precision=prec).to(dev).eval()
 i_net.update(); p_net.update()
 seq = [pad_frame(f) for f in synth_sequence(dev, 3, 1080, 1920, 0)]
 dpb = {"ref_frame": i_net.compress(seq[0], 1.0)["x_hat"], "ref_feature": None, "ref_y": None, "ref_mv_y": None}

@@ -31,11 +31,24 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
 constexpr int KC = 16;   // channels per K chunk
 constexpr int LDK = 20;  // padded channel stride of the LDS patch, in floats
+
+// Split-fp16 mode ("fp16x3"): every fp32 operand v is carried as hi = fp16(v * 2^s) and
+// lo = fp16(v * 2^s - hi); x*w ~= xh*wh + xh*wl + xl*wh on v_mfma_f32_32x32x16_f16 with fp32
+// accumulation (products of fp16 are exact in fp32; the dropped xl*wl is <= 2^-22 |x w|).
+// gfx950's MFMA honours fp16 subnormals (tools/probes/mfma_f16_subnormal.hip), so lo needs no
+// separate scale: representation error <= max(2^-22 |v|, 2^-25 / 2^s).  The power-of-two
+// pre-scales keep typical activations / weights in fp16's normal range and are undone exactly
+// in the epilogue.  3 MFMAs of 32 cycles replace 8 fp32 MFMAs of 64 cycles per 16-deep K step.
+constexpr float ACT_SCALE = 8.f;     // activations: |x| < 8188 representable
+constexpr float WGT_SCALE = 64.f;    // weights:     |w| < 1023 representable
+constexpr float F16_MAX = 65504.f;
 
 struct ConvK {
     const float *seg_ptr[DCVC_MAX_SEG];
@@ -58,18 +71,27 @@ struct ConvK {
     const float *res_gate;
     const float *res2;
     int res2_cs;
+    int vec_epi;  // 1: every output / residual row is 16-byte addressable in groups of 4 channels
 };
 
 __device__ __forceinline__ float act(float v, float slope) { return v > 0.f ? v : v * slope; }
 
-template <int KS, int S, int RPW, int NT>
-__global__ __launch_bounds__(256, 2) void conv_mfma_f32(const ConvK a) {
+__device__ __forceinline__ void split_f16(float v, _Float16 &hi, _Float16 &lo) {
+    v = fminf(fmaxf(v * ACT_SCALE, -F16_MAX), F16_MAX);
+    hi = (_Float16)v;
+    lo = (_Float16)(v - (float)hi);
+}
+
+template <int KS, int S, int RPW, int NT, bool SPLIT>
+__global__ __launch_bounds__(256, 2) void conv_mfma(const ConvK a) {
     constexpr int BH = 4 * RPW, BW = 32, BN = 32 * NT;
     constexpr int PH = (BH - 1) * S + KS, PW = (BW - 1) * S + KS, PAD = KS / 2;
     constexpr int T = KS * KS;
     constexpr int TPS = (KS == 3 && S == 1) ? 9 : KS;  // taps staged in LDS at a time
     constexpr int NST = T / TPS;
-    __shared__ __attribute__((aligned(16))) float lds[PH * PW * LDK + TPS * 4 * BN * 4];
+    constexpr int EPI_LD = BN + 4;  // floats per pixel row of the epilogue's transpose tile
+    constexpr int LDS_MAIN = PH * PW * LDK + TPS * 4 * BN * 4, LDS_EPI = 4 * 32 * EPI_LD;
+    __shared__ __attribute__((aligned(16))) float lds[LDS_MAIN > LDS_EPI ? LDS_MAIN : LDS_EPI];
     float *patch = lds;
     float *wl = lds + PH * PW * LDK;
 
@@ -144,7 +166,21 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_f32(const ConvK a) {
                     v[2] = act(v[2], a.in_slope);
                     v[3] = act(v[3], a.in_slope);
                 }
-                *(f32x4 *)&patch[(i >> 2) * LDK + (i & 3) * 4] = v;
+                if (!SPLIT) {
+                    *(f32x4 *)&patch[(i >> 2) * LDK + (i & 3) * 4] = v;
+                } else {  // pixel record: [16 x hi fp16 | 16 x lo fp16 | 16 B pad]
+                    f16x4 hi, lo;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        _Float16 h_, l_;
+                        split_f16(v[e], h_, l_);
+                        hi[e] = h_;
+                        lo[e] = l_;
+                    }
+                    _Float16 *rec = (_Float16 *)&patch[(i >> 2) * LDK];
+                    *(f16x4 *)&rec[(i & 3) * 4] = hi;
+                    *(f16x4 *)&rec[16 + (i & 3) * 4] = lo;
+                }
             }
         }
     };
@@ -175,40 +211,142 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_f32(const ConvK a) {
         __syncthreads();
         Cursor nxt = cur;
         advance(nxt);
+#ifndef PROBE_NO_LOAD
         if (nxt.s < a.nseg) {
             if (nxt.st == 0) load_patch(nxt);
             load_w(nxt);
         }
+#endif
         const int a_st = (TPS == T) ? 0 : cur.st * PW * LDK;  // staged by filter row
+#ifdef PROBE_NO_MFMA
+        if (a.Hin < 0)
+#endif
 #pragma unroll
         for (int tt = 0; tt < TPS; ++tt) {
             const int ky = (TPS == T) ? tt / KS : 0, kx = (TPS == T) ? tt % KS : tt;
+            if (!SPLIT) {
 #pragma unroll
-            for (int k2 = 0; k2 < 2; ++k2) {
-                f32x4 af[RPW], bf[NT];
-#pragma unroll
-                for (int m = 0; m < RPW; ++m)
-                    af[m] = *(const f32x4 *)&patch[a_base + a_st + ((m * S + ky) * PW + kx) * LDK + k2 * 8];
-#pragma unroll
-                for (int n = 0; n < NT; ++n)
-                    bf[n] = *(const f32x4 *)&wl[b_base + ((tt * 4 + k2 * 2) * BN + n * 32) * 4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
+                for (int k2 = 0; k2 < 2; ++k2) {
+                    f32x4 af[RPW], bf[NT];
 #pragma unroll
                     for (int m = 0; m < RPW; ++m)
+                        af[m] = *(const f32x4 *)&patch[a_base + a_st + ((m * S + ky) * PW + kx) * LDK + k2 * 8];
 #pragma unroll
-                        for (int n = 0; n < NT; ++n)
-                            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[m][j], bf[n][j], acc[m][n], 0, 0, 0);
+                    for (int n = 0; n < NT; ++n)
+                        bf[n] = *(const f32x4 *)&wl[b_base + ((tt * 4 + k2 * 2) * BN + n * 32) * 4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int m = 0; m < RPW; ++m)
+#pragma unroll
+                            for (int n = 0; n < NT; ++n)
+                                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[m][j], bf[n][j], acc[m][n], 0, 0, 0);
+                }
+            } else {
+                // lane half h holds channels 8h..8h+7: hi at float offset 4h, lo at 8 + 4h of the
+                // pixel record; filter rows are [tap][hi h0, hi h1, lo h0, lo h1][n][8 fp16]
+                f16x8 ah[RPW], al[RPW], bh[NT], bl[NT];
+#pragma unroll
+                for (int m = 0; m < RPW; ++m) {
+                    const float *rec = &patch[a_base + a_st + ((m * S + ky) * PW + kx) * LDK];
+                    ah[m] = *(const f16x8 *)rec;
+                    al[m] = *(const f16x8 *)(rec + 8);
+                }
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+                    bh[n] = *(const f16x8 *)&wl[b_base + ((tt * 4) * BN + n * 32) * 4];
+                    bl[n] = *(const f16x8 *)&wl[b_base + ((tt * 4 + 2) * BN + n * 32) * 4];
+                }
+#pragma unroll
+                for (int m = 0; m < RPW; ++m)
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) {
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[m], bh[n], acc[m][n], 0, 0, 0);
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[m], bl[n], acc[m][n], 0, 0, 0);
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[m], bh[n], acc[m][n], 0, 0, 0);
+                    }
             }
         }
         cur = nxt;
     }
 
-    // ---- epilogue: bias, activation, (gated) residual, NHWC or pixel-shuffled store
+#ifdef PROBE_NO_EPILOGUE
+    if (a.Hin > 0 && acc[0][0][0] != 12345.678f) return;
+#endif
+    // ---- epilogue: bias, activation, (gated) residual(s), NHWC or pixel-shuffled store.
     const int col = lane & 31, hh = lane >> 5;
     const int Cq = a.Cout >> 2;
     const int Cfin = a.ps ? Cq : a.Cout;
     const int Ho = a.ps ? a.Hout * 2 : a.Hout, Wo = a.ps ? a.Wout * 2 : a.Wout;
+    const float inv_scale = SPLIT ? 1.f / (ACT_SCALE * WGT_SCALE) : 1.f;
+    if (a.vec_epi) {
+        // Vector path: the MFMA leaves a channel per lane and pixels in registers; a per-wave
+        // transpose through LDS turns that into 4 consecutive channels per lane, so every
+        // global access is a 16-byte one (1 KiB per wave-instruction) and all residual loads of
+        // a row tile are in flight before the first store (res may alias out: in place is legal,
+        // each element is read and written by the same lane).
+        constexpr int LPP = BN / 4, PPI = 64 / LPP, NIT = 32 / PPI;
+        float *epi = lds + wave * 32 * EPI_LD;
+        const int c4 = (lane % LPP) * 4, pl = lane / LPP;
+        const int ch = n0 + c4;
+        const bool ch_ok = ch < a.Cout;
+        int dy = 0, dx = 0, cf = ch;
+        if (a.ps) {
+            const int sub = ch / Cq;
+            cf = ch - sub * Cq;
+            dy = sub >> 1;
+            dx = sub & 1;
+        }
+        f32x4 bias = {0.f, 0.f, 0.f, 0.f}, gate = {1.f, 1.f, 1.f, 1.f};
+        if (ch_ok) {
+            bias = *(const f32x4 *)&a.bpack[ch];
+            if (a.res_gate) gate = *(const f32x4 *)&a.res_gate[(size_t)img * Cfin + cf];
+        }
+        __syncthreads();  // main loop's LDS reads are done in every wave
+#pragma unroll
+        for (int m = 0; m < RPW; ++m) {
+            const int oy = y0 + wave * RPW + m;
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    epi[((r & 3) + 8 * (r >> 2) + 4 * hh) * EPI_LD + n * 32 + col] = acc[m][n][r];
+            __syncthreads();
+            size_t pix[NIT];
+            bool ok[NIT];
+            f32x4 rv[NIT], rv2[NIT];
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int ox = x0 + it * PPI + pl;
+                ok[it] = ch_ok && oy < a.Hout && ox < a.Wout;
+                pix[it] = a.ps ? ((size_t)(img * Ho + 2 * oy + dy) * Wo + 2 * ox + dx) : ((size_t)(img * Ho + oy) * Wo + ox);
+                rv[it] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                rv2[it] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (ok[it] && a.res) rv[it] = *(const f32x4 *)&a.res[pix[it] * a.res_cs + cf];
+                if (ok[it] && a.res2) rv2[it] = *(const f32x4 *)&a.res2[pix[it] * a.res2_cs + cf];
+            }
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                f32x4 v = *(const f32x4 *)&epi[(it * PPI + pl) * EPI_LD + c4];
+                v = v * inv_scale + bias;
+                if (a.out_act == 1) {
+                    v[0] = act(v[0], a.out_slope);
+                    v[1] = act(v[1], a.out_slope);
+                    v[2] = act(v[2], a.out_slope);
+                    v[3] = act(v[3], a.out_slope);
+                } else if (a.out_act == 2) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fminf(fmaxf(v[e], 0.f), 1.f);
+                }
+                if (a.res) v = v + (a.res_gate ? rv[it] * gate : rv[it]);
+                if (a.res2) v = rv2[it] + v;
+                if (ok[it]) *(f32x4 *)&a.out[pix[it] * a.out_cs + cf] = v;
+            }
+            __syncthreads();
+        }
+        return;
+    }
+    // Scalar path (odd channel counts / unaligned slices: 2- and 3-channel outputs).
 #pragma unroll
     for (int m = 0; m < RPW; ++m) {
         const int oy = y0 + wave * RPW + m;
@@ -226,21 +364,26 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_f32(const ConvK a) {
                 dx = sub & 1;
             }
             const float gate = a.res_gate ? a.res_gate[(size_t)img * Cfin + cf] : 1.f;
+            float rv[16], rv2[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {  // all residual loads first (res may alias out)
+                const int ox = x0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                const size_t pix = a.ps ? ((size_t)(img * Ho + 2 * oy + dy) * Wo + 2 * ox + dx)
+                                        : ((size_t)(img * Ho + oy) * Wo + ox);
+                rv[r] = (a.res && ox < a.Wout) ? a.res[pix * a.res_cs + cf] : 0.f;
+                rv2[r] = (a.res2 && ox < a.Wout) ? a.res2[pix * a.res2_cs + cf] : 0.f;
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int ox = x0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
                 if (ox >= a.Wout) continue;
-                float v = acc[m][n][r] + bias;
+                float v = acc[m][n][r] * inv_scale + bias;
                 if (a.out_act == 1) v = act(v, a.out_slope);
                 else if (a.out_act == 2) v = fminf(fmaxf(v, 0.f), 1.f);
                 const size_t pix = a.ps ? ((size_t)(img * Ho + 2 * oy + dy) * Wo + 2 * ox + dx)
                                         : ((size_t)(img * Ho + oy) * Wo + ox);
-                if (a.res) {
-                    float rv = a.res[pix * a.res_cs + cf];
-                    if (a.res_gate) rv *= gate;
-                    v += rv;
-                }
-                if (a.res2) v = a.res2[pix * a.res2_cs + cf] + v;
+                if (a.res) v += a.res_gate ? rv[r] * gate : rv[r];
+                if (a.res2) v = rv2[r] + v;
                 a.out[pix * a.out_cs + cf] = v;
             }
         }
@@ -248,10 +391,13 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_f32(const ConvK a) {
 }
 
 template <int KS, int S, int RPW, int NT>
-int launch(const ConvK &k, int N, hipStream_t st) {
+int launch(const ConvK &k, int N, hipStream_t st, int precision) {
     constexpr int BH = 4 * RPW, BN = 32 * NT;
     dim3 grid((unsigned)(((k.Wout + 31) / 32) * (k.Cout_pad / BN)), (unsigned)((k.Hout + BH - 1) / BH), (unsigned)N);
-    hipLaunchKernelGGL((conv_mfma_f32<KS, S, RPW, NT>), grid, dim3(256), 0, st, k);
+    if (precision == DCVC_PREC_FP16X3)
+        hipLaunchKernelGGL((conv_mfma<KS, S, RPW, NT, true>), grid, dim3(256), 0, st, k);
+    else
+        hipLaunchKernelGGL((conv_mfma<KS, S, RPW, NT, false>), grid, dim3(256), 0, st, k);
     return hipGetLastError() == hipSuccess ? DCVC_OK : DCVC_E_LAUNCH;
 }
 
@@ -272,7 +418,9 @@ extern "C" int64_t dcvc_conv_pack_size(int32_t Cout, int32_t ks, int32_t nseg, c
 // with n' = n, or for pixel shuffle n' = (n % 4) * (Cout/4) + n / 4 so that the four
 // sub-pixel planes are contiguous channel ranges.
 extern "C" int dcvc_conv_pack_weights(const float *w, const float *b, int32_t Cout, int32_t ks, int32_t nseg,
-                                      const int32_t *seg_C, int32_t pixel_shuffle, float *wpack, float *bpack) {
+                                      const int32_t *seg_C, int32_t pixel_shuffle, int32_t precision, float *wpack,
+                                      float *bpack) {
+    if (precision != DCVC_PREC_FP32 && precision != DCVC_PREC_FP16X3) return DCVC_E_ARG;
     int32_t cp = 0;
     const int64_t total = dcvc_conv_pack_size(Cout, ks, nseg, seg_C, &cp);
     if (total < 0 || (pixel_shuffle && (Cout & 3))) return DCVC_E_ARG;
@@ -292,8 +440,19 @@ extern "C" int dcvc_conv_pack_weights(const float *w, const float *b, int32_t Co
                         if (c >= seg_C[s]) continue;
                         for (int n = 0; n < Cout; ++n) {
                             const int np = pixel_shuffle ? (n & 3) * Cq + (n >> 2) : n;
-                            wpack[((((size_t)cg * T + t) * 4 + kq) * cp + np) * 4 + j] =
-                                w[((size_t)n * Cin + cin0 + c) * T + t];
+                            const float v = w[((size_t)n * Cin + cin0 + c) * T + t];
+                            if (precision == DCVC_PREC_FP32) {
+                                wpack[((((size_t)cg * T + t) * 4 + kq) * cp + np) * 4 + j] = v;
+                            } else {
+                                // rows [hi h0, hi h1, lo h0, lo h1], 8 fp16 per (row, n): channel 4kq+j = 8h+jj
+                                const int cc = kq * 4 + j, h = cc >> 3, jj = cc & 7;
+                                float sv = v * WGT_SCALE;
+                                sv = sv > F16_MAX ? F16_MAX : (sv < -F16_MAX ? -F16_MAX : sv);
+                                const _Float16 hi = (_Float16)sv, lo = (_Float16)(sv - (float)hi);
+                                _Float16 *base = (_Float16 *)wpack;
+                                base[((((size_t)cg * T + t) * 4 + h) * cp + np) * 8 + jj] = hi;
+                                base[((((size_t)cg * T + t) * 4 + 2 + h) * cp + np) * 8 + jj] = lo;
+                            }
                         }
                     }
         }
@@ -309,6 +468,7 @@ extern "C" int dcvc_conv_pack_weights(const float *w, const float *b, int32_t Co
 extern "C" int dcvc_conv2d(const dcvc_conv_args *a, void *stream) {
     if (!a || a->nseg < 1 || a->nseg > DCVC_MAX_SEG || !a->out || !a->wpack || !a->bpack) return DCVC_E_ARG;
     if (a->stride != 1 && a->stride != 2) return DCVC_E_ARG;
+    if (a->precision != DCVC_PREC_FP32 && a->precision != DCVC_PREC_FP16X3) return DCVC_E_ARG;
     if (a->Cout_pad % 32 || a->Cout > a->Cout_pad || (a->pixel_shuffle && (a->Cout & 3))) return DCVC_E_ARG;
     ConvK k;
     memset(&k, 0, sizeof(k));
@@ -342,15 +502,21 @@ extern "C" int dcvc_conv2d(const dcvc_conv_args *a, void *stream) {
     k.res_gate = a->res_gate;
     k.res2 = a->res2;
     k.res2_cs = a->res2_cs;
+    {
+        const int cfin = a->pixel_shuffle ? a->Cout / 4 : a->Cout;
+        auto al = [](const void *p, int cs) { return p == nullptr || ((((uintptr_t)p) & 15) == 0 && (cs & 3) == 0); };
+        k.vec_epi = (cfin % 4 == 0) && al(a->out, a->out_cs) && al(a->res, a->res_cs) && al(a->res2, a->res2_cs) &&
+                    (a->res_gate == nullptr || (((uintptr_t)a->res_gate) & 15) == 0);
+    }
     hipStream_t st = (hipStream_t)stream;
     const bool wide = (a->Cout_pad % 64) == 0;
     const int key = a->ks * 10 + a->stride;
     switch (key) {
-        case 11: return wide ? launch<1, 1, 2, 2>(k, a->N, st) : launch<1, 1, 2, 1>(k, a->N, st);
-        case 12: return wide ? launch<1, 2, 1, 2>(k, a->N, st) : launch<1, 2, 1, 1>(k, a->N, st);
-        case 31: return wide ? launch<3, 1, 2, 2>(k, a->N, st) : launch<3, 1, 2, 1>(k, a->N, st);
-        case 32: return wide ? launch<3, 2, 1, 2>(k, a->N, st) : launch<3, 2, 1, 1>(k, a->N, st);
-        case 71: return wide ? launch<7, 1, 2, 2>(k, a->N, st) : launch<7, 1, 2, 1>(k, a->N, st);
+        case 11: return wide ? launch<1, 1, 2, 2>(k, a->N, st, a->precision) : launch<1, 1, 2, 1>(k, a->N, st, a->precision);
+        case 12: return wide ? launch<1, 2, 1, 2>(k, a->N, st, a->precision) : launch<1, 2, 1, 1>(k, a->N, st, a->precision);
+        case 31: return wide ? launch<3, 1, 2, 2>(k, a->N, st, a->precision) : launch<3, 1, 2, 1>(k, a->N, st, a->precision);
+        case 32: return wide ? launch<3, 2, 1, 2>(k, a->N, st, a->precision) : launch<3, 2, 1, 1>(k, a->N, st, a->precision);
+        case 71: return wide ? launch<7, 1, 2, 2>(k, a->N, st, a->precision) : launch<7, 1, 2, 1>(k, a->N, st, a->precision);
         default: return DCVC_E_ARG;
     }
 }

@@ -56,8 +56,9 @@ class CodecBase(nn.Module):
 
     _tag = "codec"
 
-    def __init__(self, spec, seed=0):
+    def __init__(self, spec, seed=0, precision=None):
         super().__init__()
+        self.precision = precision  # None -> $DCVC_PRECISION or "fp32" (see include/dcvc_hip.h)
         build_param_tree(self, spec, seeded_state_dict(spec, seed=seed))
         self._pmap = dict(self.named_parameters())
         self._engine = None
@@ -77,9 +78,16 @@ class CodecBase(nn.Module):
     def engine(self) -> Engine:
         dev = self.device
         if self._engine is None or self._engine.device != dev:
-            self._engine = Engine(dev)  # raises without a GPU / without libdcvc_hip.so
+            self._engine = Engine(dev, self.precision)  # raises without a GPU / without libdcvc_hip.so
             self._net = Net(self._engine, self.P, self._tag)
         return self._engine
+
+    def set_precision(self, precision):
+        """'fp32' (exact fp32 MFMA, parity mode) or 'fp16x3' (split-fp16 MFMA, fast mode)."""
+        self.precision = precision
+        self._engine = None
+        self._net = None
+        return self
 
     def _qvec(self, q, N, default_param=None):
         """q-scale argument (None | float | 0-d / (N,1,1,1) tensor) -> (N,) fp32 device tensor."""
@@ -216,8 +224,8 @@ class DMC(CodecBase):
     _distribution = "laplace"
     _z_names = ("bit_estimator_z", "bit_estimator_z_mv")
 
-    def __init__(self, anchor_num=4, seed=0):
-        super().__init__(dmc_spec(anchor_num), seed=seed)
+    def __init__(self, anchor_num=4, seed=0, precision=None):
+        super().__init__(dmc_spec(anchor_num), seed=seed, precision=precision)
         self.DMC_version = "1.19"
         self.anchor_num = int(anchor_num)
         self.channel_mv, self.channel_N, self.channel_M = 64, 64, 96

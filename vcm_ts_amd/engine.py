@@ -69,11 +69,16 @@ class View:
 
 
 class PackedConv:
-    __slots__ = ("w", "b", "ks", "Cout", "Cout_pad", "seg_C", "ps", "version")
+    __slots__ = ("w", "b", "ks", "Cout", "Cout_pad", "seg_C", "ps", "version", "precision")
 
 
 class Engine:
-    def __init__(self, device):
+    def __init__(self, device, precision=None):
+        import os
+
+        self.precision = precision or os.environ.get("DCVC_PRECISION", "fp32")
+        if self.precision not in lib.PRECISIONS:
+            raise ValueError(f"precision must be one of {sorted(lib.PRECISIONS)}")
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise RuntimeError("the HIP engine needs a GPU device (no CPU fallback exists)")
@@ -149,6 +154,7 @@ class Engine:
     # ------------------------------------------------------------------ convolution
     def pack(self, key, weight: torch.Tensor, bias, seg_C, ps, cin_slice=None) -> PackedConv:
         ver = (weight._version, None if bias is None else bias._version, weight.data_ptr())
+        key = (key, self.precision)
         pk = self.packs.get(key)
         if pk is not None and pk.version == ver:
             return pk
@@ -167,12 +173,14 @@ class Engine:
         wp = np.empty(n, np.float32)
         bp = np.empty(cpad.value, np.float32)
         lib.check(self.L.dcvc_conv_pack_weights(w.ctypes.data, None if b is None else b.ctypes.data, Cout, ks,
-                                                len(seg_C), segs, int(ps), wp.ctypes.data, bp.ctypes.data),
+                                                len(seg_C), segs, int(ps), lib.PRECISIONS[self.precision],
+                                                wp.ctypes.data, bp.ctypes.data),
                   f"conv_pack_weights({key})")
         pk = PackedConv()
         pk.w = torch.from_numpy(wp).to(self.device)
         pk.b = torch.from_numpy(bp).to(self.device)
         pk.ks, pk.Cout, pk.Cout_pad, pk.seg_C, pk.ps, pk.version = ks, Cout, cpad.value, tuple(seg_C), bool(ps), ver
+        pk.precision = lib.PRECISIONS[self.precision]
         self.packs[key] = pk
         return pk
 
@@ -197,6 +205,7 @@ class Engine:
         a.out, a.out_cs = out.ptr, out.cs
         a.out_act, a.out_slope = (0, 0.0) if out_slope is None else ((2, 0.0) if out_slope == "clamp01" else (1, out_slope))
         a.pixel_shuffle = int(pk.ps)
+        a.precision = pk.precision
         if res is not None:
             assert (res.N, res.H, res.W, res.C) == (out.N, out.H, out.W, out.C)
             a.res, a.res_cs = res.ptr, res.cs

@@ -23,8 +23,8 @@ class IntraNoAR(CodecBase):
     _distribution = "gaussian"
     _z_names = ("bit_estimator_z",)
 
-    def __init__(self, N=192, anchor_num=4, seed=0):
-        super().__init__(intra_spec(N, anchor_num), seed=seed)
+    def __init__(self, N=192, anchor_num=4, seed=0, precision=None):
+        super().__init__(intra_spec(N, anchor_num), seed=seed, precision=precision)
         self.N = int(N)
         self.anchor_num = int(anchor_num)
 

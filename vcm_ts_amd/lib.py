@@ -22,7 +22,9 @@ class KernelError(RuntimeError):
 
 
 def _load(name):
-    path = os.path.join(CSRC, name)
+    # DCVC_HIP_LIB: developer override used by the kernel probes (tools/conv_probe.py) only
+    path = os.environ.get("DCVC_HIP_LIB") if name == "libdcvc_hip.so" and os.environ.get("DCVC_HIP_LIB") else \
+        os.path.join(CSRC, name)
     if not os.path.exists(path):
         raise LibraryMissing(f"{path} not built; run `make -C {CSRC}` (no CPU fallback exists)")
     return C.CDLL(path)
@@ -71,7 +73,7 @@ class ConvArgs(C.Structure):
         ("ks", C.c_int32), ("stride", C.c_int32), ("Cout", C.c_int32), ("Cout_pad", C.c_int32),
         ("out", C.c_void_p), ("out_cs", C.c_int32), ("out_act", C.c_int32), ("out_slope", C.c_float),
         ("pixel_shuffle", C.c_int32), ("res", C.c_void_p), ("res_cs", C.c_int32), ("res_gate", C.c_void_p),
-        ("res2", C.c_void_p), ("res2_cs", C.c_int32),
+        ("res2", C.c_void_p), ("res2_cs", C.c_int32), ("precision", C.c_int32),
     ]
 
 
@@ -86,12 +88,14 @@ class DualPriorArgs(C.Structure):
     ]
 
 
+PRECISIONS = {"fp32": 0, "fp16x3": 1}
+
 _hip = None
 i32, i64, f32, vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
 
 _SIGS = {
     "dcvc_conv2d": [C.POINTER(ConvArgs), vp],
-    "dcvc_conv_pack_weights": [vp, vp, i32, i32, i32, vp, i32, vp, vp],
+    "dcvc_conv_pack_weights": [vp, vp, i32, i32, i32, vp, i32, i32, vp, vp],
     "dcvc_warp": [vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, vp],
     "dcvc_up2": [vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, f32, vp],
     "dcvc_down2": [vp, i32, vp, i32, i32, i32, i32, i32, f32, i32, vp],
