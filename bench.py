@@ -26,7 +26,8 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+PEAK_F16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md, "Peak BF16/FP16 MFMA" (dense)
 
 
 def synth_sequence(dev, n, h, w, seed):
@@ -85,6 +86,8 @@ def main():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--gop", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--precision", default=os.environ.get("DCVC_PRECISION", "fp16x3"), choices=["fp32", "fp16x3"],
+                    help="convolution arithmetic: exact fp32 MFMA or split-fp16 MFMA (3 products, fp32 accumulate)")
     ap.add_argument("--cpu-size", type=int, nargs=2, default=None, help="H W of the CPU sample (default: padded full size)")
     args = ap.parse_args()
 
@@ -105,7 +108,8 @@ def main():
     from vcm_ts_amd.intra import IntraNoAR
     from vcm_ts_amd.pipeline import GopEncoder, pad_frame
 
-    i_net, p_net = IntraNoAR().to(dev).eval(), DMC().to(dev).eval()
+    i_net = IntraNoAR(precision=args.precision).to(dev).eval()
+    p_net = DMC(precision=args.precision).to(dev).eval()
     enc = GopEncoder(i_net, p_net, gop_size=args.gop)
     seq = [pad_frame(f) for f in synth_sequence(dev, args.gop, args.height, args.width, seed=rank)]
     q_i, q_mv, q_y = 1.0, 1.0, 1.0
@@ -139,20 +143,25 @@ def main():
     all_flops = sum(v["flops"] for v in prof.values())
     all_ms = sum(v["ms"] for v in prof.values())
     achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
-    roofline = {"bound": "mfma", "kernel": "conv_mfma_f32<3,1,2,*> (3x3 stride-1 convolutions)", "achieved": round(achieved, 2),
-                "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
-                "traffic": None, "launches_per_p_frame": dom["launches"] // 2,
-                "avg_launch_ms": round(dom["ms"] / max(dom["launches"], 1), 4),
-                "all_conv_tflops": round(all_flops / (all_ms * 1e-3) / 1e12, 2),
-                "conv_ms_per_p_frame": round(all_ms / 2, 2)}
+    if args.precision == "fp32":
+        peak, kname = PEAK_F32_MFMA_TFLOPS, "conv_mfma<3,1,2,*,false> (3x3 stride-1 convolutions, v_mfma_f32_32x32x2_f32)"
+        peak_note = "dense fp32 MFMA peak"
+    else:  # three fp16 MFMAs per algorithmic product: the ceiling for algorithmic FLOPs is 2500/3
+        peak, kname = PEAK_F16_MFMA_TFLOPS / 3.0, "conv_mfma<3,1,2,*,true> (3x3 stride-1 convolutions, 3 x v_mfma_f32_32x32x16_f16 per product)"
+        peak_note = "dense fp16 MFMA peak 2500 TFLOP/s / 3 MFMAs per algorithmic product"
+    roofline = {"bound": "mfma", "kernel": kname, "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
+                "frac": round(achieved / peak, 4), "peak_note": peak_note, "traffic": None,
+                "launches_per_p_frame": dom["launches"] // 2, "avg_launch_ms": round(dom["ms"] / max(dom["launches"], 1), 4),
+                "all_conv_tflops": round(all_flops / (all_ms * 1e-3) / 1e12, 2), "conv_ms_per_p_frame": round(all_ms / 2, 2)}
 
     out = {
         "metric": "encoded frames/sec at 1920x1080 GOP-32", "value": round(fps, 3), "unit": "frames/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32" if args.precision == "fp32" else "f32 (fp16x3 split-MFMA, fp32 accumulate)", "data": "synthetic",
         "config": {"workload": "1920x1080 GOP-32 synthetic sequence, single-rate encode (configs[1]); padded 1088x1920; "
                                "1 I + 31 P pictures per step per GPU; random-init name-seeded weights",
-                   "gop": args.gop, "height": args.height, "width": args.width, "parallelism": f"gop-sharded x{world}",
+                   "gop": args.gop, "height": args.height, "width": args.width, "precision": args.precision, "parallelism": f"gop-sharded x{world}",
                    "bits_per_gop": int(bits), "bpp": round(bits / (args.gop * args.height * args.width), 4)},
         "roofline": roofline,
     }

@@ -23,13 +23,15 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-4
 
 
-@pytest.fixture(scope="module")
-def nets():
+@pytest.fixture(scope="module", params=["fp32", "fp16x3"])
+def nets(request):
+    """Both arithmetic modes of the convolution kernel (include/dcvc_hip.h DCVC_PREC_*) must
+    meet the same tolerances: fp32 = exact fp32 MFMA, fp16x3 = split-fp16 MFMA."""
     from vcm_ts_amd.dmc import DMC
     from vcm_ts_amd.intra import IntraNoAR
 
     dev = torch.device("cuda:0")
-    d, i = DMC().to(dev).eval(), IntraNoAR().to(dev).eval()
+    d, i = DMC(precision=request.param).to(dev).eval(), IntraNoAR(precision=request.param).to(dev).eval()
     d.update()
     i.update()
     return d, i

@@ -51,6 +51,29 @@ def build_param_tree(root: nn.Module, spec, init):
         m.register_parameter(parts[-1], nn.Parameter(t.clone(), requires_grad=False))
 
 
+class PendingStream:
+    """Symbol planes of one picture on their way to the host: the D2H copies were enqueued on
+    the launch stream behind the kernels that produce them; finish() waits for them and runs
+    the rANS coder.  Lets the caller enqueue the next picture's kernels first (pipeline.py)."""
+
+    def __init__(self, owner, host, event, layout):
+        self.owner, self.host, self.event, self.layout = owner, host, event, layout
+        self._bytes = None
+
+    def finish(self) -> bytes:
+        if self._bytes is None:
+            self.event.synchronize()
+            ec = self.owner.entropy_coder
+            ec.reset_encoder()
+            flat = self.host.numpy()
+            for table, s_off, i_off, n, chan in self.layout:
+                cdf, ln, off = self.owner._tables[table]
+                idx = self.owner._chan_index(*chan) if i_off is None else flat[i_off : i_off + n]
+                ec.encode_with_indexes(flat[s_off : s_off + n], idx, cdf, ln, off)
+            self._bytes = ec.flush_encoder()
+        return self._bytes
+
+
 class CodecBase(nn.Module):
     """What DMC and IntraNoAR share: parameter tree, engine, q-scale plumbing, tables."""
 
@@ -66,6 +89,7 @@ class CodecBase(nn.Module):
         self.entropy_coder = None
         self._tables = None
         self._flip = 0
+        self._chan_cache, self._stage_bufs, self._stage_flip = {}, {}, 0
 
     # -- plumbing ------------------------------------------------------------------------
     def P(self, name):
@@ -148,6 +172,40 @@ class CodecBase(nn.Module):
         return c[1]
 
     # -- host <-> device symbol traffic ---------------------------------------------------
+    def _chan_index(self, N, C_, H, W):
+        key = (N, C_, H, W)
+        c = self._chan_cache.get(key)
+        if c is None:
+            c = np.ascontiguousarray(np.broadcast_to(np.arange(C_, dtype=np.int32)[None, :, None, None], (N, C_, H, W))).reshape(-1)
+            self._chan_cache[key] = c
+        return c
+
+    def _stage_symbols(self, planes) -> PendingStream:
+        """planes: list of (table name, sym int32 device tensor, idx int32 device tensor or None,
+        (N, C, H, W) for the per-channel index of factorised planes).  One pinned host buffer per
+        alternating slot; copies are asynchronous on the current stream."""
+        total = sum(p[1].numel() + (0 if p[2] is None else p[2].numel()) for p in planes)
+        slot = self._stage_flip
+        self._stage_flip ^= 1
+        key = (slot, total)
+        host = self._stage_bufs.get(key)
+        if host is None:
+            host = torch.empty(total, dtype=torch.int32, pin_memory=True)
+            self._stage_bufs[key] = host
+        layout, off = [], 0
+        for table, sym, idx, chan in planes:
+            n = sym.numel()
+            host[off : off + n].copy_(sym, non_blocking=True)
+            s_off, off = off, off + n
+            i_off = None
+            if idx is not None:
+                host[off : off + n].copy_(idx, non_blocking=True)
+                i_off, off = off, off + n
+            layout.append((table, s_off, i_off, n, chan))
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device))
+        return PendingStream(self, host, ev, layout)
+
     def _encode_factorized(self, name, sym: torch.Tensor, N, C_, H, W):
         cdf, ln, off = self._tables[name]
         s = sym.cpu().numpy()
@@ -345,25 +403,27 @@ class DMC(CodecBase):
         return self.forward_one_frame(x, dpb, mv_y_q_scale=mv_y_q_scale, y_q_scale=y_q_scale)
 
     @torch.no_grad()
-    def compress(self, x, dpb, mv_y_q_scale, y_q_scale):
+    def compress(self, x, dpb, mv_y_q_scale, y_q_scale, defer=False):
+        """defer=True returns {"dpb", "pending"}: call pending.finish() later for the bytes."""
         if self.entropy_coder is None:
             raise RuntimeError("call update() before compress()/decompress()")
         o = self._run(x, dpb, mv_y_q_scale, y_q_scale, "compress")
         N = o["N"]
         assert N == 1, "the bitstream format carries one picture per stream (video_model.py:333-340)"
-        ec = self.entropy_coder
-        ec.reset_encoder()
-        zs = o["mv_z_hat"]
-        self._encode_factorized("bit_estimator_z_mv", o["sym_mv_z"], N, 64, zs.H, zs.W)
-        for kk in (0, 1):
-            self._encode_scale(o["r_mv"]["sym"][kk], o["r_mv"]["idx"][kk])
-        zs = o["z_hat"]
-        self._encode_factorized("bit_estimator_z", o["sym_z"], N, 64, zs.H, zs.W)
-        for kk in (0, 1):
-            self._encode_scale(o["r_y"]["sym"][kk], o["r_y"]["idx"][kk])
-        bit_stream = ec.flush_encoder()
+        zm, zz = o["mv_z_hat"], o["z_hat"]
+        # bitstream order: mv_z, mv_y step 0, mv_y step 1, z, y step 0, y step 1 (video_model.py:333-340)
+        pending = self._stage_symbols([
+            ("bit_estimator_z_mv", o["sym_mv_z"], None, (N, 64, zm.H, zm.W)),
+            ("scale", o["r_mv"]["sym"][0], o["r_mv"]["idx"][0], None),
+            ("scale", o["r_mv"]["sym"][1], o["r_mv"]["idx"][1], None),
+            ("bit_estimator_z", o["sym_z"], None, (N, 64, zz.H, zz.W)),
+            ("scale", o["r_y"]["sym"][0], o["r_y"]["idx"][0], None),
+            ("scale", o["r_y"]["sym"][1], o["r_y"]["idx"][1], None),
+        ])
         d = self._dpb_out(o)
-        return {"dbp": d, "dpb": d, "bit_stream": bit_stream, "_views": o}
+        if defer:
+            return {"dbp": d, "dpb": d, "pending": pending, "_views": o}
+        return {"dbp": d, "dpb": d, "bit_stream": pending.finish(), "_views": o}
 
     @torch.no_grad()
     def decompress(self, dpb, string, height, width, mv_y_q_scale, y_q_scale):

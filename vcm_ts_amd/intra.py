@@ -73,18 +73,20 @@ class IntraNoAR(CodecBase):
                 "bpp": bpp_y + bpp_z, "bpp_y": bpp_y, "bpp_z": bpp_z, "_views": o}
 
     @torch.no_grad()
-    def compress(self, x, q_scale):
+    def compress(self, x, q_scale, defer=False):
         if self.entropy_coder is None:
             raise RuntimeError("call update() before compress()/decompress()")
         o = self._run(x, q_scale, "compress")
         assert o["N"] == 1
-        ec = self.entropy_coder
-        ec.reset_encoder()
         zs = o["z_hat"]
-        self._encode_factorized("bit_estimator_z", o["sym_z"], 1, self.N, zs.H, zs.W)
-        for k in (0, 1):
-            self._encode_scale(o["r"]["sym"][k], o["r"]["idx"][k])
-        return {"bit_stream": ec.flush_encoder(), "x_hat": o["x_hat"].nchw(), "_views": o}
+        pending = self._stage_symbols([  # image_model.py:168-171
+            ("bit_estimator_z", o["sym_z"], None, (1, self.N, zs.H, zs.W)),
+            ("scale", o["r"]["sym"][0], o["r"]["idx"][0], None),
+            ("scale", o["r"]["sym"][1], o["r"]["idx"][1], None),
+        ])
+        if defer:
+            return {"pending": pending, "x_hat": o["x_hat"].nchw(), "_views": o}
+        return {"bit_stream": pending.finish(), "x_hat": o["x_hat"].nchw(), "_views": o}
 
     @torch.no_grad()
     def decompress(self, bit_stream, height, width, q_scale):

@@ -68,20 +68,34 @@ class GopEncoder:
         q_i, qi_idx = S.get_rounded_q(q_i)
         q_mv_y, qmv_idx = S.get_rounded_q(q_mv_y)
         q_y, qy_idx = S.get_rounded_q(q_y)
-        out, bits, dpb = [], 0, None
+        out, bits, dpb, prev = [], 0, None, None
+
+        def retire(item):  # host half of a picture: wait for its planes, rANS-code them
+            nonlocal bits
+            kind, q, pending, t = item
+            payload = pending.finish()
+            out.append((kind, q, payload))
+            bits += (len(payload) + (14 if kind == "I" else 8)) * 8  # >IIHI / >HHI headers
+            if sink is not None:
+                sink(kind, q, payload, t)
+
+        # Software pipeline: the kernels of picture t are enqueued (its symbol planes follow them
+        # to pinned host memory asynchronously) BEFORE picture t-1 is entropy-coded on the host,
+        # so the GPU works on t while the CPU codes t-1.  The DPB never leaves the device.
         for t, x in enumerate(frames):
             if t % self.gop == 0:
-                r = self.i_net.compress(x, q_i)
+                r = self.i_net.compress(x, q_i, defer=True)
                 dpb = {"ref_frame": r["x_hat"], "ref_feature": None, "ref_y": None, "ref_mv_y": None}
-                out.append(("I", (qi_idx,), r["bit_stream"]))
-                bits += (len(r["bit_stream"]) + 14) * 8  # >IIHI header
+                item = ("I", (qi_idx,), r["pending"], t)
             else:
-                r = self.p_net.compress(x, dpb, q_mv_y, q_y)
+                r = self.p_net.compress(x, dpb, q_mv_y, q_y, defer=True)
                 dpb = r["dpb"]
-                out.append(("P", (qmv_idx, qy_idx), r["bit_stream"]))
-                bits += (len(r["bit_stream"]) + 8) * 8  # >HHI header
-            if sink is not None:
-                sink(*out[-1], t)
+                item = ("P", (qmv_idx, qy_idx), r["pending"], t)
+            if prev is not None:
+                retire(prev)
+            prev = item
+        if prev is not None:
+            retire(prev)
         return out, bits, dpb
 
     def decode_gop(self, coded, height, width):
