@@ -58,6 +58,17 @@ def host_cores():
     return max(1, min(n, 16))
 
 
+def pmc_traffic(precision):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (profiles/*_pmc_traffic.json, written by tools/rocprof_traffic.py with the gfx950 FETCH_SIZE
+    x2 correction of MI355X_MICROARCH.md); bench.py cannot run the profiler on itself."""
+    path = os.path.join(ROOT, "profiles", f"pmc_traffic_{precision}.json")
+    try:
+        return json.load(open(path))["bytes_per_launch"]
+    except (OSError, ValueError, KeyError):
+        return None
+
+
 def cpu_baseline(h, w, threads):
     """One 1088x1920 P-picture through the CPU oracle's networks (dmc_analysis) = the nets of
     DMC.compress; bounded sample so the default run stays within minutes."""
@@ -150,7 +161,8 @@ def main():
         peak, kname = PEAK_F16_MFMA_TFLOPS / 3.0, "conv_mfma<3,1,2,*,true> (3x3 stride-1 convolutions, 3 x v_mfma_f32_32x32x16_f16 per product)"
         peak_note = "dense fp16 MFMA peak 2500 TFLOP/s / 3 MFMAs per algorithmic product"
     roofline = {"bound": "mfma", "kernel": kname, "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
-                "frac": round(achieved / peak, 4), "peak_note": peak_note, "traffic": None,
+                "frac": round(achieved / peak, 4), "peak_note": peak_note, "traffic": pmc_traffic(args.precision),
+                "algorithmic_bytes_per_launch": round(dom.get("bytes", 0.0) / max(dom["launches"], 1)),
                 "launches_per_p_frame": dom["launches"] // 2, "avg_launch_ms": round(dom["ms"] / max(dom["launches"], 1), 4),
                 "all_conv_tflops": round(all_flops / (all_ms * 1e-3) / 1e12, 2), "conv_ms_per_p_frame": round(all_ms / 2, 2)}
 

@@ -127,7 +127,8 @@ int dcvc_nhwc_to_nchw(const float *src, int32_t src_cs, float *out, int32_t N, i
                       int32_t clamp01, void *stream);
 
 /* ---- squeeze-excitation ---------------------------------------------------------------- */
-/* mean(n, c) over H*W of a strided NHWC tensor, deterministic two-pass; scratch >= N*256*C floats */
+/* mean(n, c) over H*W of a strided NHWC tensor (C a power of two in [4, 256]), deterministic
+ * two-pass; scratch >= N*2048*C floats */
 int dcvc_channel_mean(const float *src, int32_t src_cs, float *mean, float *scratch, int32_t N, int32_t HW,
                       int32_t C, void *stream);
 /* gate = sigmoid(W2 relu(W1 mean)); W1: (Cr, C), W2: (C, Cr) as nn.Linear stores them */

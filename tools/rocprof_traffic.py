@@ -1,0 +1,25 @@
+"""HBM traffic per launch of the dominant kernel from two rocprofv3 PMC passes (FETCH_SIZE and
+WRITE_SIZE in separate runs, as MI355X_MICROARCH.md prescribes).  FETCH_SIZE is doubled: on
+gfx950 it reports half the bytes of wide (16 B/lane) coalesced streaming reads; WRITE_SIZE is
+exact for 16 B/lane stores.  Both counters are in KB.
+    python tools/rocprof_traffic.py fetch.db write.db 'conv_mfma<3, 1, 2, 2, true>' fp16x3"""
+import json, os, sqlite3, sys
+
+def avg(path, counter, pattern):
+    c = sqlite3.connect(path)
+    r = c.execute("select count(*), avg(counter_value), avg(duration) from pmc_events where counter_name=? and name like ?",
+                  (counter, f"%{pattern}%")).fetchone()
+    return r
+
+def main(fdb, wdb, pattern, precision):
+    nf, f, df = avg(fdb, "FETCH_SIZE", pattern)
+    nw, w, dw = avg(wdb, "WRITE_SIZE", pattern)
+    out = {"kernel": pattern, "launches_sampled": nf, "fetch_size_kb_raw": f, "fetch_bytes_corrected_x2": 2 * f * 1024,
+           "write_bytes": w * 1024, "bytes_per_launch": round(2 * f * 1024 + w * 1024), "avg_duration_us_fetch_pass": df / 1e3,
+           "avg_duration_us_write_pass": dw / 1e3, "note": "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B requests at 64 B)"}
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    json.dump(out, open(os.path.join(root, "profiles", f"pmc_traffic_{precision}.json"), "w"), indent=1)
+    print(json.dumps(out, indent=1))
+
+if __name__ == "__main__":
+    main(*sys.argv[1:5])

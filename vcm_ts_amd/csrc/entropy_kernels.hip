@@ -16,13 +16,15 @@
 
 #include "dcvc_hip.h"
 
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
 namespace {
 
 #define RET_LAUNCH() return hipGetLastError() == hipSuccess ? DCVC_OK : DCVC_E_LAUNCH
 inline unsigned nblk(int64_t n, int b) { return (unsigned)((n + b - 1) / b); }
 
 constexpr int RB = 1024;  // partial-sum blocks per sample for scalar reductions
-constexpr int MB = 256;   // partial-sum blocks per sample for channel means
+constexpr int MB = 2048;  // partial-sum blocks per sample for channel means
 
 __device__ __forceinline__ float block_sum(float v, float *sm) {
     const int t = threadIdx.x;
@@ -45,22 +47,25 @@ __global__ void finish_sum(const float *__restrict__ scratch, float *__restrict_
 }
 
 // ---- SE ------------------------------------------------------------------------------------
+// Per-channel partial sums over a slice of pixels: 16 B per lane (4 channels), MB blocks per
+// sample so the read runs at HBM rate; partials are reduced in a fixed order (no atomics).
 __global__ void channel_partial(const float *__restrict__ src, int cs, float *__restrict__ scratch, int HW, int C) {
-    __shared__ float sm[256];
+    __shared__ f32x4 sm[256];
     const int n = blockIdx.y, b = blockIdx.x, t = threadIdx.x;
-    const int G = 256 / C;  // pixel groups per block (C divides 256 or C <= 256)
-    const int c = t % C, g = t / C;
+    const int C4 = C >> 2;           // lanes per pixel
+    const int G = 256 / C4;          // pixels per block iteration
+    const int c4 = t % C4, g = t / C4;
     const int per = (HW + MB - 1) / MB;
     const int p0 = b * per, p1 = min(HW, p0 + per);
-    float v = 0.f;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
     if (g < G)
-        for (int p = p0 + g; p < p1; p += G) v += src[((size_t)n * HW + p) * cs + c];
+        for (int p = p0 + g; p < p1; p += G) v += *(const f32x4 *)&src[((size_t)n * HW + p) * cs + c4 * 4];
     sm[t] = v;
     __syncthreads();
-    if (t < C) {
-        float s = 0.f;
-        for (int k = 0; k < G; ++k) s += sm[k * C + t];
-        scratch[((size_t)n * MB + b) * C + t] = s;
+    if (t < C4) {
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        for (int k = 0; k < G; ++k) s += sm[k * C4 + t];
+        *(f32x4 *)&scratch[((size_t)n * MB + b) * C + t * 4] = s;
     }
 }
 
@@ -286,7 +291,9 @@ __global__ void sq_err_kernel(const float *__restrict__ a, int a_cs, const float
 
 extern "C" int dcvc_channel_mean(const float *src, int32_t src_cs, float *mean, float *scratch, int32_t N, int32_t HW,
                                  int32_t C, void *stream) {
-    if (!src || !mean || !scratch || N <= 0 || HW <= 0 || C <= 0 || C > 256 || (256 % C)) return DCVC_E_ARG;
+    if (!src || !mean || !scratch || N <= 0 || HW <= 0 || C < 4 || C > 256 || (1024 % C) || (src_cs & 3) ||
+        ((uintptr_t)src & 15))
+        return DCVC_E_ARG;
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(channel_partial, dim3(MB, N), dim3(256), 0, st, src, src_cs, scratch, HW, C);
     hipLaunchKernelGGL(channel_finish, dim3(N), dim3(256), 0, st, scratch, mean, HW, C);

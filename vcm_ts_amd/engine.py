@@ -222,7 +222,10 @@ class Engine:
             lib.check(self.L.dcvc_conv2d(C.byref(a), self.stream()), "conv2d")
             ev1.record()
             flops = 2.0 * s0.N * Ho * Wo * pk.Cout * sum(pk.seg_C) * pk.ks * pk.ks  # algorithmic, unpadded
-            self.profile.setdefault(f"conv{pk.ks}x{pk.ks}s{stride}", []).append((ev0, ev1, flops))
+            nout = s0.N * Ho * Wo * pk.Cout
+            abytes = 4.0 * (s0.N * s0.H * s0.W * sum(pk.seg_C) + nout * (1 + (res is not None) + (res2 is not None))
+                            + pk.Cout * sum(pk.seg_C) * pk.ks * pk.ks)  # each operand once
+            self.profile.setdefault(f"conv{pk.ks}x{pk.ks}s{stride}", []).append((ev0, ev1, flops, abytes))
             if self.profile_detail is not None:
                 self.profile_detail.append((ev0, ev1, flops, f"k{pk.ks}s{stride} {pk.seg_C}->{pk.Cout}{'ps' if pk.ps else ''} "
                                                              f"{s0.H}x{s0.W}"))
@@ -231,7 +234,8 @@ class Engine:
 
     def collect_profile(self):
         torch.cuda.synchronize(self.device)
-        return {k: {"flops": sum(f for _, _, f in v), "ms": sum(a.elapsed_time(b) for a, b, _ in v), "launches": len(v)}
+        return {k: {"flops": sum(r[2] for r in v), "bytes": sum(r[3] for r in v),
+                    "ms": sum(r[0].elapsed_time(r[1]) for r in v), "launches": len(v)}
                 for k, v in (self.profile or {}).items()}
 
     # ------------------------------------------------------------------ resampling
@@ -268,7 +272,7 @@ class Engine:
     # ------------------------------------------------------------------ SE
     def se_gate(self, name, t: View, w1: torch.Tensor, w2: torch.Tensor) -> torch.Tensor:
         N, C_ = t.N, t.C
-        scratch = self.fbuf("se_scratch", N * 256 * 256)
+        scratch = self.fbuf("se_scratch", N * 2048 * 256)
         mean = self.fbuf(name + ".mean", N * C_)
         gate = self.fbuf(name + ".gate", N * C_)
         lib.check(self.L.dcvc_channel_mean(t.ptr, t.cs, mean.data_ptr(), scratch.data_ptr(), N, t.HW, C_,
