@@ -24,7 +24,6 @@
 // A and B use the same permutation, so the sum is unchanged.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
-#include <stdlib.h>
 #include <string.h>
 #include <vector>
 
@@ -403,468 +402,9 @@ __global__ __launch_bounds__(256, CLASSIC_WAVES_PER_SIMD) void conv_mfma(const C
 }
 
 
-// =================================================================================================
-// conv_ws: persistent, wave-specialised variant of the same implicit GEMM.
-//
-// One 512-thread workgroup per CU loops over output tiles (XCD-contiguous ranges, so the 32 CUs
-// of an XCD work on neighbouring tiles and share halos / filters in their L2).  Waves 0-3 are
-// CONSUMERS: they only read LDS and issue MFMAs (same fragment maps as conv_mfma), then run the
-// epilogue.  Waves 4-7 are PRODUCERS: they stage the next step one iteration ahead into the
-// other half of double-buffered LDS -- filters by LDS-DMA (global_load_lds_dwordx4: no VGPRs, no
-// ds_write), the input patch through registers (it needs the fp32 -> fp16 hi/lo conversion in
-// split mode and zero fill at the borders).  One s_barrier per step; because producers run ahead
-// across tile boundaries, the consumers' epilogue of tile i overlaps the staging of tile i+1.
-//   LDS: 2 x patch + 2 x filter slab + 18 KiB epilogue transpose (3x3: 146.5 KiB, 7x7: 157 KiB).
-// =================================================================================================
-struct TileCur {
-    int i;        // position in this block's tile list
-    int x0, y0, n0, img;
-    bool valid;
-};
-
-struct StepCur {
-    TileCur t;
-    int s, c0, cg, st;  // segment, first channel of the chunk, global chunk index, tap stage
-    bool valid;
-};
-
-template <int KS, int S, int RPW, int NT, bool SPLIT>
-__global__ __launch_bounds__(512, 2) void conv_ws(const ConvK a, int tiles_x, int tiles_y, int total_tiles) {
-    constexpr int BH = 4 * RPW, BW = 32, BN = 32 * NT;
-    constexpr int PH = (BH - 1) * S + KS, PW = (BW - 1) * S + KS, PAD = KS / 2;
-    constexpr int T = KS * KS;
-    constexpr int TPS = (KS == 3 && S == 1) ? 9 : KS;
-    constexpr int NST = T / TPS;
-    constexpr int PATCH_F = PH * PW * LDK, W_F = TPS * 4 * BN * 4, EPI_LD = 36, EPI_F = 4 * 32 * EPI_LD;
-    __shared__ __attribute__((aligned(16))) float lds[2 * PATCH_F + 2 * W_F + EPI_F];
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const bool producer = wave >= 4;
-    const int nbn = a.Cout_pad / BN;
-
-    // ---- tile schedule: XCD x (blockIdx % 8) owns the contiguous tile range [x*R, (x+1)*R)
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;
-    const int R = (total_tiles + 7) >> 3;
-    auto tile_at = [&](int i) {
-        TileCur t;
-        t.i = i;
-        int id = xcd * R + i;
-        t.valid = i < R && id < total_tiles;
-        const int nb = id % nbn;
-        id /= nbn;
-        const int tx = id % tiles_x;
-        id /= tiles_x;
-        const int ty = id % tiles_y;
-        t.img = id / tiles_y;
-        t.x0 = tx * BW;
-        t.y0 = ty * BH;
-        t.n0 = nb * BN;
-        return t;
-    };
-    auto first_step = [&](const TileCur &t) {
-        StepCur k;
-        k.t = t;
-        k.s = 0;
-        k.c0 = 0;
-        k.cg = 0;
-        k.st = 0;
-        k.valid = t.valid;
-        return k;
-    };
-    auto next_chunk = [&](StepCur k) {  // first step of the chunk after k's (possibly in the next tile)
-        k.st = 0;
-        ++k.cg;
-        k.c0 += KC;
-        if (k.c0 >= a.seg_C[k.s]) {
-            ++k.s;
-            k.c0 = 0;
-            if (k.s >= a.nseg) k = first_step(tile_at(k.t.i + per_xcd));
-        }
-        return k;
-    };
-    auto next_step = [&](StepCur k) {
-        if (k.st + 1 < NST) {
-            ++k.st;
-            return k;
-        }
-        return next_chunk(k);
-    };
-
-    StepCur cur = first_step(tile_at(slot));
-    if (!cur.valid) return;  // uniform over the block: no barrier has been executed yet
-
-    if (producer) {
-        // ------------------------------------------------------------------ PRODUCER waves
-        const int ptid = tid - 256;
-        constexpr int NP = (PH * PW * 4 + 255) / 256, NWD = (TPS * 4 * BN + 255) / 256;
-        f32x4 rp[NP];
-        bool okm[NP];
-        auto load_patch = [&](const StepCur &k) {
-            // Every lane issues exactly NP loads (out-of-range lanes read the segment's first
-            // texel and are zeroed below): the producers' counted s_waitcnt relies on that number.
-            const int C = a.seg_C[k.s], cs = a.seg_cs[k.s];
-            const float *sp = a.seg_ptr[k.s] + (size_t)k.t.img * a.Hin * a.Win * cs;
-#pragma unroll
-            for (int u = 0; u < NP; ++u) {
-                const int i = ptid + u * 256;
-                const int p = i >> 2, q = i & 3;
-                const int py = p / PW, px = p - py * PW;
-                const int gy = k.t.y0 * S - PAD + py, gx = k.t.x0 * S - PAD + px;
-                const int c = k.c0 + q * 4;
-                const bool ok = i < PH * PW * 4 && gy >= 0 && gy < a.Hin && gx >= 0 && gx < a.Win && c < C;
-                const float *src = ok ? sp + ((size_t)gy * a.Win + gx) * cs + c : sp;
-                rp[u] = *(const f32x4 *)src;
-                okm[u] = ok;
-            }
-        };
-        auto store_patch = [&](const StepCur &k, float *patch) {
-            const int C = a.seg_C[k.s];
-#pragma unroll
-            for (int u = 0; u < NP; ++u) {
-                const int i = ptid + u * 256;
-                if (i < PH * PW * 4) {
-                    const int c = k.c0 + (i & 3) * 4;
-                    f32x4 v = okm[u] ? rp[u] : (f32x4){0.f, 0.f, 0.f, 0.f};
-                    if (c + 3 >= C) {
-                        if (c + 1 >= C) v[1] = 0.f;
-                        if (c + 2 >= C) v[2] = 0.f;
-                        v[3] = 0.f;
-                    }
-                    if (a.in_act) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = act(v[e], a.in_slope);
-                    }
-                    if (!SPLIT) {
-                        *(f32x4 *)&patch[(i >> 2) * LDK + (i & 3) * 4] = v;
-                    } else {
-                        f16x4 hi, lo;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            _Float16 h_, l_;
-                            split_f16(v[e], h_, l_);
-                            hi[e] = h_;
-                            lo[e] = l_;
-                        }
-                        _Float16 *rec = (_Float16 *)&patch[(i >> 2) * LDK];
-                        *(f16x4 *)&rec[(i & 3) * 4] = hi;
-                        *(f16x4 *)&rec[16 + (i & 3) * 4] = lo;
-                    }
-                }
-            }
-        };
-        auto dma_w = [&](const StepCur &k, float *wl) {
-            const float *wsrc = a.wpack + ((size_t)(k.cg * T + k.st * TPS) * 4) * a.Cout_pad * 4 + (size_t)k.t.n0 * 4;
-#pragma unroll
-            for (int u = 0; u < NWD; ++u) {
-                const int i0 = u * 256 + (wave - 4) * 64;  // wave-uniform: LDS-DMA writes base + lane * 16
-                if (i0 < TPS * 4 * BN) {
-                    const int i = i0 + lane;
-                    const int row = i / BN, col = i - row * BN;
-                    __builtin_amdgcn_global_load_lds(
-                        (const __attribute__((address_space(1))) void *)(wsrc + ((size_t)row * a.Cout_pad + col) * 4),
-                        (__attribute__((address_space(3))) void *)(wl + i0 * 4), 16, 0, 0);
-                }
-            }
-        };
-        // End of a producer iteration: the filter DMA and the ds_writes of this step must have
-        // landed; the NP patch loads issued after the DMA (youngest VMEM ops, always exactly NP
-        // per lane) stay in flight across the barrier -- they are consumed one iteration later.
-        auto sync = [&](bool patch_loads_in_flight) {
-            if (patch_loads_in_flight)
-                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NP) : "memory");
-            else
-                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-        };
-
-        int g = 0, q = 0;
-        StepCur pl = cur;  // the chunk whose patch is (being) held in registers
-        load_patch(pl);
-        store_patch(pl, lds);
-        dma_w(cur, lds + 2 * PATCH_F);
-        pl = next_chunk(pl);
-        if (pl.valid) load_patch(pl);
-        sync(pl.valid);  // barrier #0
-        while (true) {
-            const StepCur nxt = next_step(cur);
-            if (!nxt.valid) {
-                __builtin_amdgcn_s_barrier();  // matches the consumers' barrier after the last step
-                break;
-            }
-            bool inflight = false;
-            if (nxt.st == 0) {  // a new chunk starts at step g+1: its patch is in rp
-                ++q;
-                store_patch(nxt, lds + (q & 1) * PATCH_F);
-                pl = next_chunk(nxt);
-            }
-            dma_w(nxt, lds + 2 * PATCH_F + ((g + 1) & 1) * W_F);
-            if (nxt.st == 0 && pl.valid) {
-                load_patch(pl);
-                inflight = true;
-            }
-            sync(inflight);
-            cur = nxt;
-            ++g;
-        }
-        return;
-    }
-
-    // ---------------------------------------------------------------------- CONSUMER waves
-    const int a_base = ((wave * RPW * S) * PW + (lane & 31) * S) * LDK + (lane >> 5) * 4;
-    const int b_base = ((lane >> 5) * BN + (lane & 31)) * 4;
-    const int col = lane & 31, hh = lane >> 5;
-    const int Cq = a.Cout >> 2;
-    const int Cfin = a.ps ? Cq : a.Cout;
-    const int Ho = a.ps ? a.Hout * 2 : a.Hout, Wo = a.ps ? a.Wout * 2 : a.Wout;
-    const float inv_scale = SPLIT ? 1.f / (ACT_SCALE * WGT_SCALE) : 1.f;
-    float *epi = lds + 2 * PATCH_F + 2 * W_F + wave * 32 * EPI_LD;
-
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();  // barrier #0: step 0 is staged
-    int g = 0, q = 0;
-    while (cur.valid) {
-        const TileCur tile = cur.t;
-        f32x16 acc[RPW][NT];
-#pragma unroll
-        for (int m = 0; m < RPW; ++m)
-#pragma unroll
-            for (int n = 0; n < NT; ++n)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
-        // residual tile prefetch: issued before the MFMAs of the tile's LAST step so that the
-        // loads' latency is hidden behind them (64 VGPRs for RPW x NT x 4 float4)
-        constexpr int LPP = 8, PPI = 8, NIT = 4;  // epilogue geometry: 32-channel halves, 16 B per lane
-        const int e_c4 = (lane % LPP) * 4, e_pl = lane / LPP;
-        f32x4 rv[RPW][NT][NIT];
-        bool rv_loaded = false;
-        while (true) {
-            const float *patch = lds + (q & 1) * PATCH_F;
-            const float *wl = lds + 2 * PATCH_F + (g & 1) * W_F;
-            const int a_st = (TPS == T) ? 0 : cur.st * PW * LDK;
-            {
-                const StepCur peek = next_step(cur);
-                if (a.vec_epi && a.res && !(peek.valid && peek.t.i == tile.i)) {
-                    rv_loaded = true;
-#pragma unroll
-                    for (int m = 0; m < RPW; ++m) {
-                        const int oy = tile.y0 + wave * RPW + m;
-#pragma unroll
-                        for (int n = 0; n < NT; ++n) {
-                            const int ch = tile.n0 + n * 32 + e_c4;
-                            int dy = 0, dx = 0, cf = ch;
-                            if (a.ps) {
-                                const int sub = ch / Cq;
-                                cf = ch - sub * Cq;
-                                dy = sub >> 1;
-                                dx = sub & 1;
-                            }
-#pragma unroll
-                            for (int it = 0; it < NIT; ++it) {
-                                const int ox = tile.x0 + it * PPI + e_pl;
-                                const bool ok = ch < a.Cout && oy < a.Hout && ox < a.Wout;
-                                const size_t pix = a.ps ? ((size_t)(tile.img * Ho + 2 * oy + dy) * Wo + 2 * ox + dx)
-                                                        : ((size_t)(tile.img * Ho + oy) * Wo + ox);
-                                rv[m][n][it] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                                if (ok) rv[m][n][it] = *(const f32x4 *)&a.res[pix * a.res_cs + cf];
-                            }
-                        }
-                    }
-                }
-            }
-            // Software pipeline over "units" (a tap in split mode, half a tap in fp32 mode): the
-            // fragments of unit u+1 are requested from LDS before the MFMAs of unit u issue, so a
-            // single consumer wave per SIMD never waits on ds_read latency inside a step.
-            if (!SPLIT) {
-                constexpr int NU = TPS * 2;
-                f32x4 af[2][RPW], bf[2][NT];
-                auto rd = [&](int u, int sl) {
-                    const int tt = u >> 1, k2 = u & 1;
-                    const int ky = (TPS == T) ? tt / KS : 0, kx = (TPS == T) ? tt % KS : tt;
-#pragma unroll
-                    for (int m = 0; m < RPW; ++m)
-                        af[sl][m] = *(const f32x4 *)&patch[a_base + a_st + ((m * S + ky) * PW + kx) * LDK + k2 * 8];
-#pragma unroll
-                    for (int n = 0; n < NT; ++n)
-                        bf[sl][n] = *(const f32x4 *)&wl[b_base + ((tt * 4 + k2 * 2) * BN + n * 32) * 4];
-                };
-                rd(0, 0);
-#pragma unroll
-                for (int u = 0; u < NU; ++u) {
-                    if (u + 1 < NU) rd(u + 1, (u + 1) & 1);
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-#pragma unroll
-                        for (int m = 0; m < RPW; ++m)
-#pragma unroll
-                            for (int n = 0; n < NT; ++n)
-                                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[u & 1][m][j], bf[u & 1][n][j], acc[m][n], 0, 0, 0);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            } else {
-                f16x8 ah[2][RPW], al[2][RPW], bh[2][NT], bl[2][NT];
-                auto rd = [&](int tt, int sl) {
-                    const int ky = (TPS == T) ? tt / KS : 0, kx = (TPS == T) ? tt % KS : tt;
-#pragma unroll
-                    for (int m = 0; m < RPW; ++m) {
-                        const float *rec = &patch[a_base + a_st + ((m * S + ky) * PW + kx) * LDK];
-                        ah[sl][m] = *(const f16x8 *)rec;
-                        al[sl][m] = *(const f16x8 *)(rec + 8);
-                    }
-#pragma unroll
-                    for (int n = 0; n < NT; ++n) {
-                        bh[sl][n] = *(const f16x8 *)&wl[b_base + ((tt * 4) * BN + n * 32) * 4];
-                        bl[sl][n] = *(const f16x8 *)&wl[b_base + ((tt * 4 + 2) * BN + n * 32) * 4];
-                    }
-                };
-                rd(0, 0);
-#pragma unroll
-                for (int tt = 0; tt < TPS; ++tt) {
-                    if (tt + 1 < TPS) rd(tt + 1, (tt + 1) & 1);
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int m = 0; m < RPW; ++m)
-#pragma unroll
-                        for (int n = 0; n < NT; ++n) {
-                            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tt & 1][m], bh[tt & 1][n], acc[m][n], 0, 0, 0);
-                            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tt & 1][m], bl[tt & 1][n], acc[m][n], 0, 0, 0);
-                            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[tt & 1][m], bh[tt & 1][n], acc[m][n], 0, 0, 0);
-                        }
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this step's LDS reads are done
-            __builtin_amdgcn_s_barrier();
-            const StepCur nxt = next_step(cur);
-            ++g;
-            const bool same_tile = nxt.valid && nxt.t.i == tile.i;
-            if (nxt.valid && nxt.st == 0) ++q;
-            cur = nxt;
-            if (!same_tile) break;
-        }
-
-        // ---- epilogue of `tile` (overlaps the producers' staging of the next tile)
-        const int x0 = tile.x0, y0 = tile.y0, n0 = tile.n0, img = tile.img;
-        if (a.vec_epi) {
-            const int c4 = e_c4, pl_ = e_pl;
-#pragma unroll
-            for (int m = 0; m < RPW; ++m) {
-                const int oy = y0 + wave * RPW + m;
-#pragma unroll
-                for (int n = 0; n < NT; ++n) {
-                    const int ch = n0 + n * 32 + c4;
-                    const bool ch_ok = ch < a.Cout;
-                    int dy = 0, dx = 0, cf = ch;
-                    if (a.ps) {
-                        const int sub = ch / Cq;
-                        cf = ch - sub * Cq;
-                        dy = sub >> 1;
-                        dx = sub & 1;
-                    }
-                    f32x4 bias = {0.f, 0.f, 0.f, 0.f}, gate = {1.f, 1.f, 1.f, 1.f};
-                    if (ch_ok) {
-                        bias = *(const f32x4 *)&a.bpack[ch];
-                        if (a.res_gate) gate = *(const f32x4 *)&a.res_gate[(size_t)img * Cfin + cf];
-                    }
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) epi[((r & 3) + 8 * (r >> 2) + 4 * hh) * EPI_LD + col] = acc[m][n][r];
-                    size_t pix[NIT];
-                    bool ok[NIT];
-                    f32x4 rv2[NIT];
-#pragma unroll
-                    for (int it = 0; it < NIT; ++it) {
-                        const int ox = x0 + it * PPI + pl_;
-                        ok[it] = ch_ok && oy < a.Hout && ox < a.Wout;
-                        pix[it] = a.ps ? ((size_t)(img * Ho + 2 * oy + dy) * Wo + 2 * ox + dx) : ((size_t)(img * Ho + oy) * Wo + ox);
-                        rv2[it] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                        if (ok[it] && a.res2) rv2[it] = *(const f32x4 *)&a.res2[pix[it] * a.res2_cs + cf];
-                    }
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // wave-private tile: own ds_writes done
-#pragma unroll
-                    for (int it = 0; it < NIT; ++it) {
-                        f32x4 v = *(const f32x4 *)&epi[(it * PPI + pl_) * EPI_LD + c4];
-                        v = v * inv_scale + bias;
-                        if (a.out_act == 1) {
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) v[e] = act(v[e], a.out_slope);
-                        } else if (a.out_act == 2) {
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) v[e] = fminf(fmaxf(v[e], 0.f), 1.f);
-                        }
-                        if (rv_loaded) v = v + (a.res_gate ? rv[m][n][it] * gate : rv[m][n][it]);
-                        if (a.res2) v = rv2[it] + v;
-                        if (ok[it]) *(f32x4 *)&a.out[pix[it] * a.out_cs + cf] = v;
-                    }
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // reads done before the tile is rewritten
-                }
-            }
-        } else {
-#pragma unroll
-            for (int m = 0; m < RPW; ++m) {
-                const int oy = y0 + wave * RPW + m;
-                if (oy >= a.Hout) continue;
-#pragma unroll
-                for (int n = 0; n < NT; ++n) {
-                    const int ch = n0 + n * 32 + col;
-                    if (ch >= a.Cout) continue;
-                    const float bias = a.bpack[ch];
-                    int dy = 0, dx = 0, cf = ch;
-                    if (a.ps) {
-                        const int sub = ch / Cq;
-                        cf = ch - sub * Cq;
-                        dy = sub >> 1;
-                        dx = sub & 1;
-                    }
-                    const float gate = a.res_gate ? a.res_gate[(size_t)img * Cfin + cf] : 1.f;
-                    float rv[16], rv2[16];
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int ox = x0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-                        const size_t pix = a.ps ? ((size_t)(img * Ho + 2 * oy + dy) * Wo + 2 * ox + dx)
-                                                : ((size_t)(img * Ho + oy) * Wo + ox);
-                        rv[r] = (a.res && ox < a.Wout) ? a.res[pix * a.res_cs + cf] : 0.f;
-                        rv2[r] = (a.res2 && ox < a.Wout) ? a.res2[pix * a.res2_cs + cf] : 0.f;
-                    }
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int ox = x0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-                        if (ox >= a.Wout) continue;
-                        float v = acc[m][n][r] * inv_scale + bias;
-                        if (a.out_act == 1) v = act(v, a.out_slope);
-                        else if (a.out_act == 2) v = fminf(fmaxf(v, 0.f), 1.f);
-                        const size_t pix = a.ps ? ((size_t)(img * Ho + 2 * oy + dy) * Wo + 2 * ox + dx)
-                                                : ((size_t)(img * Ho + oy) * Wo + ox);
-                        if (a.res) v += a.res_gate ? rv[r] * gate : rv[r];
-                        if (a.res2) v = rv2[r] + v;
-                        a.out[pix * a.out_cs + cf] = v;
-                    }
-                }
-            }
-        }
-    }
-}
-
-bool use_classic() {
-    static const bool v = [] {
-        const char *e = getenv("DCVC_CONV_IMPL");
-        return !(e && strcmp(e, "ws") == 0);
-    }();
-    return v;
-}
-
 template <int KS, int S, int RPW, int NT>
 int launch(const ConvK &k, int N, hipStream_t st, int precision) {
     constexpr int BH = 4 * RPW, BN = 32 * NT;
-    if (!use_classic()) {
-        const int tiles_x = (k.Wout + 31) / 32, tiles_y = (k.Hout + BH - 1) / BH;
-        const int total = N * tiles_y * tiles_x * (k.Cout_pad / BN);
-        const int grid = total >= 256 ? 256 : (total + 7) / 8 * 8;  // one persistent workgroup per CU
-        if (precision == DCVC_PREC_FP16X3)
-            hipLaunchKernelGGL((conv_ws<KS, S, RPW, NT, true>), dim3(grid), dim3(512), 0, st, k, tiles_x, tiles_y, total);
-        else
-            hipLaunchKernelGGL((conv_ws<KS, S, RPW, NT, false>), dim3(grid), dim3(512), 0, st, k, tiles_x, tiles_y, total);
-        return hipGetLastError() == hipSuccess ? DCVC_OK : DCVC_E_LAUNCH;
-    }
     dim3 grid((unsigned)(((k.Wout + 31) / 32) * (k.Cout_pad / BN)), (unsigned)((k.Hout + BH - 1) / BH), (unsigned)N);
     if (precision == DCVC_PREC_FP16X3)
         hipLaunchKernelGGL((conv_mfma<KS, S, RPW, NT, true>), grid, dim3(256), 0, st, k);
