@@ -72,7 +72,7 @@ def test_split_fp16_conv_matches_fp64(eng_split, case):
     if use_res or use_res2:
         pytest.skip("epilogue identical to the fp32 kernel; covered there")
     eng = eng_split
-    g = torch.Generator().manual_seed(hash(case) % 1000 + 7)
+    g = torch.Generator().manual_seed(CONV_CASES.index(case) + 7)
     N = 1
     cin = sum(segs)
     mag = torch.tensor([1e-4, 1.0, 30.0])[torch.randint(0, 3, (N, cin, 1, 1), generator=g)]
@@ -90,13 +90,14 @@ def test_split_fp16_conv_matches_fp64(eng_split, case):
     out = eng.buf("t64/out", N, want.shape[2], want.shape[3], cout)
     eng.conv(pk, views, out, stride=stride, in_slope=in_slope)
     got = eng.to_nchw(out).cpu().double()
-    assert (got - want).abs().max().item() < 3e-6 * scale
+    # 3e-6 of the accumulated magnitude + the fp32 rounding of the stored result itself
+    assert (got - want).abs().max().item() < 3e-6 * scale + 2e-7 * want.abs().max().item()
 
 
 @pytest.mark.parametrize("case", CONV_CASES, ids=[f"c{i}" for i in range(len(CONV_CASES))])
 def test_conv_matches_torch(eng, case):
     segs, cout, ks, stride, H, W, ps, in_slope, out_slope, use_res, use_gate, use_res2 = case
-    g = torch.Generator().manual_seed(hash(case) % 1000)
+    g = torch.Generator().manual_seed(CONV_CASES.index(case))
     N = 2
     xs = [torch.randn(N, c, H, W, generator=g) for c in segs]
     cin = sum(segs)

@@ -70,11 +70,19 @@ __global__ void channel_partial(const float *__restrict__ src, int cs, float *__
 }
 
 __global__ void channel_finish(const float *__restrict__ scratch, float *__restrict__ mean, int HW, int C) {
-    const int n = blockIdx.x, c = threadIdx.x;
-    if (c >= C) return;
+    __shared__ float sm[256];
+    const int n = blockIdx.x, t = threadIdx.x;
+    const int c = t % C, part = t / C, P = 256 / C;  // P interleaved partial sums per channel, fixed order
     float s = 0.f;
-    for (int b = 0; b < MB; ++b) s += scratch[((size_t)n * MB + b) * C + c];
-    mean[(size_t)n * C + c] = s / (float)HW;
+    if (part < P)
+        for (int b = part; b < MB; b += P) s += scratch[((size_t)n * MB + b) * C + c];
+    sm[t] = s;
+    __syncthreads();
+    if (t < C) {
+        float r = 0.f;
+        for (int k = 0; k < P; ++k) r += sm[k * C + t];
+        mean[(size_t)n * C + t] = r / (float)HW;
+    }
 }
 
 __global__ void se_gate_kernel(const float *__restrict__ mean, const float *__restrict__ w1,
