@@ -97,6 +97,7 @@ def main():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--gop", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) on a multi-GPU node; gloo to rehearse on one GPU")
     ap.add_argument("--precision", default=os.environ.get("DCVC_PRECISION", "fp16x3"), choices=["fp32", "fp16x3"],
                     help="convolution arithmetic: exact fp32 MFMA or split-fp16 MFMA (3 products, fp32 accumulate)")
     ap.add_argument("--cpu-size", type=int, nargs=2, default=None, help="H W of the CPU sample (default: padded full size)")
@@ -109,10 +110,10 @@ def main():
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", init_method="env://")
+        dist.init_process_group(backend=args.dist_backend, init_method="env://")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
-    dev = torch.device("cuda", local)
+    dev = torch.device("cuda", local % torch.cuda.device_count())
     torch.cuda.set_device(dev)
 
     from vcm_ts_amd.dmc import DMC

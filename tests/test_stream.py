@@ -1,0 +1,49 @@
+"""Geometry helpers and `.bin` wire format (vcm_ts_amd/stream.py) against values and bytes
+produced by the reference's own stream_helper.py (tests/golden/stream.npz)."""
+import os
+
+import numpy as np
+import pytest
+
+from tests.util import golden
+from vcm_ts_amd import stream as S
+
+
+def test_geometry_and_q_rounding_match_reference():
+    fx = golden("stream")
+    for (h, w), pad, d16, d64 in zip(fx["sizes"], fx["padding"], fx["down16"], fx["down64"]):
+        assert S.get_padding_size(int(h), int(w)) == tuple(int(v) for v in pad)
+        assert S.get_downsampled_shape(int(h), int(w), 16) == tuple(int(v) for v in d16)
+        assert S.get_downsampled_shape(int(h), int(w), 64) == tuple(int(v) for v in d64)
+    for q, qs, qi in zip(fx["q_in"], fx["q_scale"], fx["q_index"]):
+        got_s, got_i = S.get_rounded_q(float(q))
+        assert got_i == int(qi) and got_s == pytest.approx(float(qs), abs=0)
+
+
+def test_bin_files_are_byte_identical_to_reference(tmp_path):
+    fx = golden("stream")
+    payload = fx["payload"].tobytes()
+    p = os.path.join(tmp_path, "p.bin")
+    S.encode_p(payload, 123, 45678, p)
+    assert open(p, "rb").read() == fx["bin_p"].tobytes()
+    assert S.decode_p(p) == (123, 45678, payload)
+    S.encode_i(1080, 1920, 150, payload, p)
+    assert open(p, "rb").read() == fx["bin_i"].tobytes()
+    assert S.decode_i(p) == (1080, 1920, 150, payload)
+    assert S.filesize(p) == len(fx["bin_i"])
+    # empty payload and error path
+    S.encode_p(b"", 1, 2, p)
+    assert S.decode_p(p) == (1, 2, b"")
+    with pytest.raises(ValueError):
+        S.filesize(os.path.join(tmp_path, "missing.bin"))
+
+
+def test_pad_frame_matches_reference_padding():
+    import torch
+
+    from vcm_ts_amd.pipeline import pad_frame
+
+    x = torch.rand(1, 3, 1080, 1920)
+    y = pad_frame(x)
+    assert y.shape == (1, 3, 1088, 1920)
+    assert torch.equal(y[..., :1080, :], x) and float(y[..., 1080:, :].abs().max()) == 0.0

@@ -49,7 +49,8 @@ def timed_region(fn, device=None):
     fence()
     dt = time.time() - t0
     if multi:
-        t = torch.tensor([dt], dtype=torch.float64, device=device if device is not None else "cpu")
+        on_gpu = device is not None and dist.get_backend() == "nccl"
+        t = torch.tensor([dt], dtype=torch.float64, device=device if on_gpu else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     return dt, result
