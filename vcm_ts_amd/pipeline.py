@@ -62,10 +62,11 @@ class GopEncoder:
         self.i_net.update()
         self.p_net.update()
 
-    def encode_gop(self, frames, q_i, q_mv_y, q_y, sink=None):
+    def encode_gop(self, frames, q_i, q_mv_y, q_y, sink=None, on_recon=None):
         """frames: iterable of padded (1, 3, H, W) device tensors, the first coded as an I
         picture.  Returns (list of payload bytes with their headers' q indexes, total bits of
-        the payloads + headers).  `sink(kind, index, header_fields, payload)` may persist them."""
+        the payloads + headers, final DPB).  `sink(kind, q_indexes, payload, t)` may persist the
+        coded pictures; `on_recon(t, ref_frame)` sees each reconstruction while it is still valid."""
         q_i, qi_idx = S.get_rounded_q(q_i)
         q_mv_y, qmv_idx = S.get_rounded_q(q_mv_y)
         q_y, qy_idx = S.get_rounded_q(q_y)
@@ -92,6 +93,8 @@ class GopEncoder:
                 r = self.p_net.compress(x, dpb, q_mv_y, q_y, defer=True)
                 dpb = r["dpb"]
                 item = ("P", (qmv_idx, qy_idx), r["pending"], t)
+            if on_recon is not None:  # reconstruction == what the decoder will produce (clamped)
+                on_recon(t, dpb["ref_frame"])
             if prev is not None:
                 retire(prev)
             prev = item

@@ -1,0 +1,159 @@
+"""Folder-level encode / decode: the base-layer loop of the reference's
+``video_coder.run_dcvc`` (/root/reference/video_coder.py:80-155) and its PNG conventions
+(DCVC_HEM/src/utils/png_reader.py:10-46, stream_helper.py:148-153) on the MI355X path.
+
+    python -m vcm_ts_amd.run_codec encode --frames DIR --bins DIR [--recon DIR] [--gop 32] [--q 1.0 1.0 1.0]
+    python -m vcm_ts_amd.run_codec decode --bins DIR --recon DIR --height H --width W
+
+Frames are ``im1.png`` / ``im00001.png`` ...; coded pictures are ``im00001.bin`` ... in the
+reference's `.bin` format (an I picture every `gop` frames).  Unlike run_dcvc the encoder does not
+run the decoder: its own reconstruction is bit-identical to what `decode` produces.
+"""
+from __future__ import annotations
+
+import argparse
+import os
+
+import numpy as np
+import torch
+from PIL import Image
+
+from . import stream as S
+from .pipeline import GopEncoder, pad_frame
+
+
+class PNGReader:
+    """im1.png or im00001.png naming, RGB float32 in [0, 1], (3, H, W)."""
+
+    def __init__(self, folder):
+        names = os.listdir(folder)
+        if "im1.png" in names:
+            self.width = 1
+        elif "im00001.png" in names:
+            self.width = 5
+        else:
+            raise ValueError("unknown image naming convention; expected im1.png or im00001.png")
+        self.folder, self.index = folder, 1
+
+    def read_one_frame(self):
+        path = os.path.join(self.folder, f"im{str(self.index).zfill(self.width)}.png")
+        if not os.path.exists(path):
+            return None
+        self.index += 1
+        return np.asarray(Image.open(path).convert("RGB")).astype("float32").transpose(2, 0, 1) / 255.0
+
+
+def save_torch_image(img: torch.Tensor, path):
+    a = img.squeeze(0).permute(1, 2, 0).detach().cpu().numpy()
+    Image.fromarray(np.clip(np.rint(a * 255), 0, 255).astype(np.uint8)).save(path)
+
+
+def _nets(device, precision, i_ckpt=None, p_ckpt=None):
+    from .dmc import DMC
+    from .intra import IntraNoAR
+
+    i_net, p_net = IntraNoAR(precision=precision), DMC(precision=precision)
+    if i_ckpt:
+        i_net.load_state_dict(S.get_state_dict(i_ckpt), strict=False)
+    if p_ckpt:
+        p_net.load_state_dict(S.get_state_dict(p_ckpt), strict=False)
+    return i_net.to(device).eval(), p_net.to(device).eval()
+
+
+def encode_folder(frames_dir, bin_dir, recon_dir=None, gop=32, q=(1.0, 1.0, 1.0), device="cuda:0", precision=None,
+                  i_ckpt=None, p_ckpt=None, max_frames=None):
+    """Returns (bits per frame list, (height, width))."""
+    os.makedirs(bin_dir, exist_ok=True)
+    if recon_dir:
+        os.makedirs(recon_dir, exist_ok=True)
+    dev = torch.device(device)
+    enc = GopEncoder(*_nets(dev, precision, i_ckpt, p_ckpt), gop_size=gop)
+    reader = PNGReader(frames_dir)
+    size, bits = [None], []
+
+    def frames():
+        n = 0
+        while max_frames is None or n < max_frames:
+            rgb = reader.read_one_frame()
+            if rgb is None:
+                return
+            x = torch.from_numpy(rgb)[None].to(dev)
+            if size[0] is None:
+                size[0] = tuple(x.shape[-2:])
+            assert tuple(x.shape[-2:]) == size[0], "all frames must have one size"
+            n += 1
+            yield pad_frame(x)
+
+    def sink(kind, qidx, payload, t):
+        path = os.path.join(bin_dir, f"im{str(t + 1).zfill(5)}.bin")
+        if kind == "I":
+            S.encode_i(size[0][0], size[0][1], qidx[0], payload, path)
+        else:
+            S.encode_p(payload, qidx[0], qidx[1], path)
+        bits.append(S.filesize(path) * 8)
+
+    def on_recon(t, ref_frame):
+        if recon_dir:
+            h, w = size[0]
+            save_torch_image(ref_frame[..., :h, :w], os.path.join(recon_dir, f"im{str(t + 1).zfill(5)}.png"))
+
+    with torch.no_grad():
+        enc.encode_gop(frames(), q[0], q[1], q[2], sink=sink, on_recon=on_recon)
+    return bits, size[0]
+
+
+def decode_folder(bin_dir, recon_dir, height, width, gop=32, device="cuda:0", precision=None, i_ckpt=None, p_ckpt=None):
+    os.makedirs(recon_dir, exist_ok=True)
+    dev = torch.device(device)
+    i_net, p_net = _nets(dev, precision, i_ckpt, p_ckpt)
+    i_net.update()
+    p_net.update()
+    t, dpb = 0, None
+    with torch.no_grad():
+        while True:
+            path = os.path.join(bin_dir, f"im{str(t + 1).zfill(5)}.bin")
+            if not os.path.exists(path):
+                break
+            if t % gop == 0:
+                h, w, qi, payload = S.decode_i(path)
+                assert (h, w) == (height, width)
+                x_hat = i_net.decompress(payload, h, w, qi / 100)["x_hat"]
+                dpb = {"ref_frame": x_hat, "ref_feature": None, "ref_y": None, "ref_mv_y": None}
+            else:
+                qmv, qy, payload = S.decode_p(path)
+                dpb = p_net.decompress(dpb, payload, height, width, qmv / 100, qy / 100)["dpb"]
+            save_torch_image(dpb["ref_frame"][..., :height, :width], os.path.join(recon_dir, f"im{str(t + 1).zfill(5)}.png"))
+            t += 1
+    return t
+
+
+def main():
+    ap = argparse.ArgumentParser(description=__doc__.split("\n")[0])
+    sub = ap.add_subparsers(dest="cmd", required=True)
+    e = sub.add_parser("encode")
+    e.add_argument("--frames", required=True)
+    e.add_argument("--bins", required=True)
+    e.add_argument("--recon")
+    e.add_argument("--q", type=float, nargs=3, default=(1.0, 1.0, 1.0), metavar=("I", "MV_Y", "Y"))
+    d = sub.add_parser("decode")
+    d.add_argument("--bins", required=True)
+    d.add_argument("--recon", required=True)
+    d.add_argument("--height", type=int, required=True)
+    d.add_argument("--width", type=int, required=True)
+    for p in (e, d):
+        p.add_argument("--gop", type=int, default=32)
+        p.add_argument("--device", default="cuda:0")
+        p.add_argument("--precision", default=None, choices=["fp32", "fp16x3"])
+        p.add_argument("--i-ckpt")
+        p.add_argument("--p-ckpt")
+    a = ap.parse_args()
+    if a.cmd == "encode":
+        bits, size = encode_folder(a.frames, a.bins, a.recon, a.gop, tuple(a.q), a.device, a.precision, a.i_ckpt, a.p_ckpt)
+        print(f"{len(bits)} pictures, {size[0]}x{size[1]}, {sum(bits)} bits, {sum(bits) / (len(bits) * size[0] * size[1]):.4f} bpp")
+    else:
+        n = decode_folder(a.bins, a.recon, a.height, a.width, a.gop, a.device, a.precision, a.i_ckpt, a.p_ckpt)
+        print(f"{n} pictures decoded")
+
+
+if __name__ == "__main__":
+    main()
