@@ -76,6 +76,18 @@ struct ConvK {
 
 __device__ __forceinline__ float act(float v, float slope) { return v > 0.f ? v : v * slope; }
 
+#ifdef PROBE_STAMP
+// developer probe: per-workgroup s_memtime stamps of the main-loop phases (tools/conv_stamps.py)
+__device__ unsigned long long *g_stamps;
+#define STAMP(k)                                                                              \
+    do {                                                                                      \
+        if (tid == 0 && stamp_i < 62) g_stamps[(size_t)(blockIdx.x + gridDim.x * blockIdx.y) * 64 + 2 + stamp_i++] = \
+            __builtin_amdgcn_s_memtime();                                                     \
+    } while (0)
+#else
+#define STAMP(k)
+#endif
+
 __device__ __forceinline__ void split_f16(float v, _Float16 &hi, _Float16 &lo) {
     v = fminf(fmaxf(v * ACT_SCALE, -F16_MAX), F16_MAX);
     hi = (_Float16)v;
@@ -211,15 +223,22 @@ __global__ __launch_bounds__(256, CLASSIC_WAVES_PER_SIMD) void conv_mfma(const C
     };
 
     Cursor cur = {0, 0, 0, 0};
+#ifdef PROBE_STAMP
+    int stamp_i = 0;
+#endif
+    STAMP(0);
     load_patch(cur);
     load_w(cur);
     while (cur.s < a.nseg) {
         __syncthreads();  // every wave is done reading the previous step's LDS
+        STAMP(1);
 #ifndef PROBE_NO_STORE
         if (cur.st == 0) store_patch(cur);
         store_w();
 #endif
+        STAMP(2);
         __syncthreads();
+        STAMP(3);
         Cursor nxt = cur;
         advance(nxt);
 #ifndef PROBE_NO_LOAD
@@ -278,6 +297,7 @@ __global__ __launch_bounds__(256, CLASSIC_WAVES_PER_SIMD) void conv_mfma(const C
                     }
             }
         }
+        STAMP(4);
         cur = nxt;
     }
 
@@ -355,6 +375,7 @@ __global__ __launch_bounds__(256, CLASSIC_WAVES_PER_SIMD) void conv_mfma(const C
             }
             __syncthreads();
         }
+        STAMP(5);
         return;
     }
     // Scalar path (odd channel counts / unaligned slices: 2- and 3-channel outputs).
@@ -416,6 +437,10 @@ int launch(const ConvK &k, int N, hipStream_t st, int precision) {
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
 }  // namespace
+
+#ifdef PROBE_STAMP
+extern "C" int dcvc_probe_set_stamps(void *p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), &p, sizeof(p)); }
+#endif
 
 extern "C" int64_t dcvc_conv_pack_size(int32_t Cout, int32_t ks, int32_t nseg, const int32_t *seg_C, int32_t *cout_pad) {
     if (Cout <= 0 || nseg <= 0 || nseg > DCVC_MAX_SEG || (ks != 1 && ks != 3 && ks != 7)) return DCVC_E_ARG;
