@@ -152,21 +152,28 @@ __global__ __launch_bounds__(256, CLASSIC_WAVES_PER_SIMD) void conv_mfma(const C
             }
         }
     };
+    // Per-lane patch geometry is the same for every chunk: precompute the pixel offset and an
+    // in-picture bit per staged float4; out-of-picture lanes load pixel 0 (valid memory) and are
+    // zeroed when the registers are written to LDS, so the loads carry no branches.
+    int poff[NP];
+    unsigned inpic = 0;
+#pragma unroll
+    for (int u = 0; u < NP; ++u) {
+        const int i = tid + u * 256;
+        const int p = i >> 2;
+        const int py = p / PW, px = p - py * PW;
+        const int gy = y0 * S - PAD + py, gx = x0 * S - PAD + px;
+        const bool ok = i < PH * PW * 4 && gy >= 0 && gy < a.Hin && gx >= 0 && gx < a.Win;
+        poff[u] = ok ? gy * a.Win + gx : 0;
+        inpic |= (ok ? 1u : 0u) << u;
+    }
     auto load_patch = [&](const Cursor &k) {
         const int C = a.seg_C[k.s], cs = a.seg_cs[k.s];
         const float *sp = a.seg_ptr[k.s] + (size_t)img * a.Hin * a.Win * cs;
+        const int c = k.c0 + (tid & 3) * 4;
+        const int cc = c < C ? c : 0;  // chunk tail: load channel 0, zeroed at store time
 #pragma unroll
-        for (int u = 0; u < NP; ++u) {
-            const int i = tid + u * 256;
-            const int p = i >> 2, q = i & 3;
-            const int py = p / PW, px = p - py * PW;
-            const int gy = y0 * S - PAD + py, gx = x0 * S - PAD + px;
-            const int c = k.c0 + q * 4;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (i < PH * PW * 4 && gy >= 0 && gy < a.Hin && gx >= 0 && gx < a.Win && c < C)
-                v = *(const f32x4 *)(sp + ((size_t)gy * a.Win + gx) * cs + c);
-            rp[u] = v;
-        }
+        for (int u = 0; u < NP; ++u) rp[u] = *(const f32x4 *)(sp + (size_t)poff[u] * cs + cc);
     };
     auto store_patch = [&](const Cursor &k) {
         const int C = a.seg_C[k.s];
@@ -175,7 +182,7 @@ __global__ __launch_bounds__(256, CLASSIC_WAVES_PER_SIMD) void conv_mfma(const C
             const int i = tid + u * 256;
             if (i < PH * PW * 4) {
                 const int c = k.c0 + (i & 3) * 4;
-                f32x4 v = rp[u];
+                f32x4 v = ((inpic >> u) & 1u) && c < C ? rp[u] : (f32x4){0.f, 0.f, 0.f, 0.f};
                 if (c + 3 >= C) {  // channels past the segment's end read as zero
                     if (c + 1 >= C) v[1] = 0.f;
                     if (c + 2 >= C) v[2] = 0.f;
@@ -190,14 +197,12 @@ __global__ __launch_bounds__(256, CLASSIC_WAVES_PER_SIMD) void conv_mfma(const C
                 if (!SPLIT) {
                     *(f32x4 *)&patch[(i >> 2) * LDK + (i & 3) * 4] = v;
                 } else {  // pixel record: [16 x hi fp16 | 16 x lo fp16 | 16 B pad]
-                    f16x4 hi, lo;
+                    // vector form: the compiler emits packed converts (v_cvt_pk_f16_f32, v_pk_*)
+                    f32x4 sv = v * ACT_SCALE;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        _Float16 h_, l_;
-                        split_f16(v[e], h_, l_);
-                        hi[e] = h_;
-                        lo[e] = l_;
-                    }
+                    for (int e = 0; e < 4; ++e) sv[e] = __builtin_amdgcn_fmed3f(sv[e], -F16_MAX, F16_MAX);
+                    const f16x4 hi = __builtin_convertvector(sv, f16x4);
+                    const f16x4 lo = __builtin_convertvector(sv - __builtin_convertvector(hi, f32x4), f16x4);
                     _Float16 *rec = (_Float16 *)&patch[(i >> 2) * LDK];
                     *(f16x4 *)&rec[(i & 3) * 4] = hi;
                     *(f16x4 *)&rec[16 + (i & 3) * 4] = lo;
@@ -342,7 +347,9 @@ __global__ __launch_bounds__(256, CLASSIC_WAVES_PER_SIMD) void conv_mfma(const C
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
                     epi[((r & 3) + 8 * (r >> 2) + 4 * hh) * EPI_LD + n * 32 + col] = acc[m][n][r];
-            __syncthreads();
+            // the transpose tile is private to this wave and a wave's LDS operations execute in
+            // order: draining its own ds_writes is all the synchronisation the reads below need
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             size_t pix[NIT];
             bool ok[NIT];
             f32x4 rv[NIT], rv2[NIT];
@@ -373,7 +380,7 @@ __global__ __launch_bounds__(256, CLASSIC_WAVES_PER_SIMD) void conv_mfma(const C
                 if (a.res2) v = rv2[it] + v;
                 if (ok[it]) *(f32x4 *)&a.out[pix[it] * a.out_cs + cf] = v;
             }
-            __syncthreads();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // reads done before the tile is rewritten
         }
         STAMP(5);
         return;
