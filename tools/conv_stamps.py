@@ -27,8 +27,11 @@ names = ["start"] + sum([[f"c{c}:B1", f"c{c}:store", f"c{c}:B2", f"c{c}:mfma"] f
 n = len(names)
 d = np.diff(t[:, :n], axis=1)
 t0 = t[:, 0].min()
-print(f"{nblk} workgroups; kernel span {(t[:, n-1].max() - t0):.0f} ticks of s_memtime (100 MHz): {1e-5*(t[:, n-1].max()-t0):.3f} ms")
+print(f"{nblk} workgroups; s_memtime counts shader cycles")
+real = (s[:, 1] - s[:, 0]).astype(np.float64)  # s_memrealtime ticks (100 MHz) over the workgroup's life
 life = t[:, n - 1] - t[:, 0]
+clk = life / real * 100.0
+print(f"in-kernel shader clock: median {np.median(clk):.0f} MHz (p10 {np.percentile(clk,10):.0f}, p90 {np.percentile(clk,90):.0f})")
 print(f"workgroup lifetime: median {np.median(life):.0f} ticks, p10 {np.percentile(life,10):.0f}, p90 {np.percentile(life,90):.0f}")
 for k in range(n - 1):
     print(f"  {names[k]:>10s} -> {names[k+1]:<10s} median {np.median(d[:, k]):7.0f}  p90 {np.percentile(d[:, k], 90):7.0f} ticks")

@@ -230,6 +230,7 @@ __global__ __launch_bounds__(256, CLASSIC_WAVES_PER_SIMD) void conv_mfma(const C
     Cursor cur = {0, 0, 0, 0};
 #ifdef PROBE_STAMP
     int stamp_i = 0;
+    if (tid == 0) g_stamps[(size_t)(blockIdx.x + gridDim.x * blockIdx.y) * 64] = __builtin_amdgcn_s_memrealtime();
 #endif
     STAMP(0);
     load_patch(cur);
@@ -383,6 +384,9 @@ __global__ __launch_bounds__(256, CLASSIC_WAVES_PER_SIMD) void conv_mfma(const C
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // reads done before the tile is rewritten
         }
         STAMP(5);
+#ifdef PROBE_STAMP
+        if (tid == 0) g_stamps[(size_t)(blockIdx.x + gridDim.x * blockIdx.y) * 64 + 1] = __builtin_amdgcn_s_memrealtime();
+#endif
         return;
     }
     // Scalar path (odd channel counts / unaligned slices: 2- and 3-channel outputs).
