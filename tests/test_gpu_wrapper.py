@@ -1,0 +1,117 @@
+"""DCVC_HEM wrapper (vcm_ts_amd/dcvc_hem.py) in evaluation mode against the loss assembly
+restated from /root/reference/core/model/dcvc_hem.py over the CPU oracle's forward_one_frame."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import dcvc_ref as R
+from tests.util import oracle_weights
+from vcm_ts_amd.synthetic import frames
+
+pytestmark = pytest.mark.gpu
+LAMBDAS = (85.0, 380.0)
+
+
+@pytest.fixture(scope="module")
+def model():
+    from vcm_ts_amd.dcvc_hem import build_model, make_cfg
+
+    return build_model(make_cfg(lambdas=LAMBDAS, dist_lambda=1.0, pl_lambda=0.5)).cuda().eval()
+
+
+def _clip(n=2, t=3, h=64, w=64):
+    return torch.from_numpy(np.stack([frames(30 + i, t, h, w) for i in range(n)]))  # (N, T, 3, H, W)
+
+
+def _oracle_losses(x, p_frames, rate_keys, dist_key):
+    """rate / dist / loss per (t_i, p) with dpb starting from the input frame (dcvc_hem.py:181-208)."""
+    from vcm_ts_amd.params import dmc_spec, seeded_state_dict
+
+    w = seeded_state_dict(dmc_spec(anchor_num=len(LAMBDAS)))  # the wrapper builds DMC(anchor_num=len(lambdas))
+    lam = torch.tensor(LAMBDAS)
+    out = []
+    for t_i in range(x.shape[1] - p_frames):
+        dpb = {"ref_frame": x[:, t_i], "ref_feature": None, "ref_y": None, "ref_mv_y": None}
+        row = []
+        for p in range(p_frames):
+            o = R.dmc_forward_one_frame(w, x[:, t_i + 1 + p], dpb, w["mv_y_q_scale"][:2], w["y_q_scale"][:2])
+            dpb = o["dpb"]
+            rate = sum((o[k] for k in rate_keys), torch.zeros(2))
+            row.append((rate, o[dist_key], rate + lam * (o[dist_key] * 1.0), dpb["ref_frame"]))
+        out.append(row)
+    return out
+
+
+def test_single_and_cascade_match_oracle(model):
+    x = _clip()
+    want = _oracle_losses(x, 2, ["bpp_y", "bpp_mv_y"], "mse")
+    xg = x.cuda()
+    with torch.no_grad():
+        s = model("single", xg, xg, "mse", ["bpp_y", "bpp_mv_y"], p_frames=2, perceptual_loss=False, is_train=False)
+        c = model("cascade", xg, xg, "mse", ["bpp_y", "bpp_mv_y"], p_frames=2, perceptual_loss=False, is_train=False)
+    assert s["rate"].shape == (2, 2) and s["loss_seq"].shape == (2, 1) and s["single_forwards"] == 2
+    assert s["input_seqs"].shape == (2, 1, 3, 3, 64, 64) and s["decod_seqs"].shape == (2, 1, 3, 3, 64, 64)
+    for p in range(2):
+        rate, dist, loss, rec = want[0][p]
+        np.testing.assert_allclose(s["rate"][:, p].cpu().numpy(), rate.numpy(), rtol=1e-4)
+        np.testing.assert_allclose(s["dist"][:, p].cpu().numpy(), dist.numpy(), rtol=1e-4)
+        np.testing.assert_allclose(s["loss"][:, p].cpu().numpy(), loss.numpy(), rtol=1e-4)
+        np.testing.assert_allclose(s["decod_seqs"][:, 0, p + 1].cpu().numpy(), rec.numpy(), atol=5e-5)
+    np.testing.assert_allclose(s["loss_seq"][:, 0].cpu().numpy(), torch.stack([want[0][0][2], want[0][1][2]], -1).mean(-1).numpy(), rtol=1e-4)
+    assert torch.equal(s["input_seqs"][:, 0, 0].cpu(), x[:, 0]) and float(s["p_dist"].abs().max()) == 0.0
+    # cascade: means over the p frames of one sub-sequence (:440-452)
+    assert c["rate"].shape == (2, 1) and c["single_forwards"] == 1
+    np.testing.assert_allclose(c["loss"][:, 0].cpu().numpy(), s["loss"].mean(-1).cpu().numpy(), rtol=1e-5)
+    np.testing.assert_allclose(c["dist"][:, 0].cpu().numpy(), s["dist"].mean(-1).cpu().numpy(), rtol=1e-5)
+
+
+def test_single_multi_simple_and_perceptual_hook(model):
+    x = _clip(t=2).cuda()
+    dpb = {"ref_frame": x[:, 0], "ref_feature": None, "ref_y": None, "ref_mv_y": None}
+    with torch.no_grad():
+        r = model("single_multi", x[:, 1], x[:, 1], "mse", ["bpp"], dpb=dpb, perceptual_loss=False)
+    assert set(r) == {"rate", "dist", "p_dist", "loss", "loss_to_opt", "input_seqs", "decod_seqs", "dpb"}
+    assert r["loss_to_opt"].shape == () and r["dpb"]["ref_feature"].shape == (2, 64, 64, 64)
+    torch.testing.assert_close(r["loss"], r["rate"] + model.lambdas * r["dist"])
+    # no rate keys -> lambdas are replaced by ones (:148)
+    dpb2 = {"ref_frame": x[:, 0], "ref_feature": None, "ref_y": None, "ref_mv_y": None}
+    with torch.no_grad():
+        r2 = model("single_multi", x[:, 1], x[:, 1], "mse", [], dpb=dpb2, perceptual_loss=False)
+    torch.testing.assert_close(r2["loss"], r2["dist"])
+    # pluggable perceptual term
+    model.perceptual_loss = lambda target, recon: (target - recon).abs().mean(dim=(1, 2, 3))
+    dpb3 = {"ref_frame": x[:, 0], "ref_feature": None, "ref_y": None, "ref_mv_y": None}
+    with torch.no_grad():
+        r3 = model("single_multi", x[:, 1], x[:, 1], "mse", ["bpp"], dpb=dpb3, perceptual_loss=True)
+    torch.testing.assert_close(r3["loss"], r3["rate"] + model.lambdas * (r3["dist"] + 0.5 * r3["p_dist"]))
+    model.perceptual_loss = None
+    # forward_simple: one sample (rate point) at a time, list of dpbs
+    seq = x[:, 1:2]  # (N, 1, 3, H, W): input[i] is (1, 3, H, W)
+    dpbs = [{"ref_frame": x[i : i + 1, 0], "ref_feature": None, "ref_y": None, "ref_mv_y": None} for i in range(2)]
+    with torch.no_grad():
+        out = model("forward_simple", seq, dpb=dpbs)
+    assert len(out) == 2 and out[0]["ref_y"].shape == (1, 96, 4, 4)
+    torch.testing.assert_close(out[1]["ref_frame"], r["dpb"]["ref_frame"][1:2], rtol=1e-4, atol=1e-5)
+
+
+def test_training_is_refused_and_groups(model):
+    x = _clip(t=2).cuda()
+    with pytest.raises(NotImplementedError):
+        model("single", x, x, "mse", ["bpp"], p_frames=1, perceptual_loss=False, is_train=True)
+    with pytest.raises(ValueError):
+        model("nope", x)
+    model.activate_modules_inter_dist()
+    on = {n for n, p in model.dmc.named_parameters() if p.requires_grad}
+    assert on and all(n.startswith(("bit_estimator_z_mv", "mv_", "optic_flow")) for n in on) and "mv_y_q_scale" not in on
+    model.activate_modules_inter_dist_rate()
+    assert {"mv_y_q_basic", "mv_y_q_scale"} <= {n for n, p in model.dmc.named_parameters() if p.requires_grad}
+    model.activate_modules_recon_dist()
+    on = {n for n, p in model.dmc.named_parameters() if p.requires_grad}
+    assert "y_q_scale" not in on and "contextual_encoder.conv1.weight" in on and "optic_flow.moduleBasic.0.conv1.weight" not in on
+    model.activate_modules_recon_dist_rate()
+    assert "y_q_scale" in {n for n, p in model.dmc.named_parameters() if p.requires_grad}
+    model.activate_modules_all()
+    assert all(p.requires_grad for p in model.dmc.parameters())
+    assert all(k.startswith("dmc.") for k in model.state_dict())
+    for p in model.dmc.parameters():
+        p.requires_grad = False
