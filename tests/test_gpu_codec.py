@@ -183,6 +183,8 @@ def test_requires_update_and_padding(nets):
         fresh.compress(x, dpb, 1.0, 1.0)
     with pytest.raises(AssertionError):
         fresh.forward_one_frame(torch.rand(1, 3, 60, 64).cuda(), dpb, 1.0, 1.0)
+    with pytest.raises(RuntimeError):  # training-mode forward (noise + STE) is not built: refuse loudly
+        fresh.train().forward_one_frame(x, dpb, 1.0, 1.0)
 
 
 def test_full_size_properties(nets):

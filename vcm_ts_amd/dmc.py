@@ -113,6 +113,13 @@ class CodecBase(nn.Module):
         self._net = None
         return self
 
+    def _eval_only(self):
+        """The reference's training-mode forward adds uniform noise to the latents for the bit
+        estimate and uses a straight-through round (common_model.py:38-49, video_model.py:546-550);
+        neither that nor backward is built yet, so refuse rather than silently return eval numbers."""
+        if self.training:
+            raise RuntimeError("training-mode forward is not built on the HIP path in this round: call .eval() first")
+
     def _qvec(self, q, N, default_param=None):
         """q-scale argument (None | float | 0-d / (N,1,1,1) tensor) -> (N,) fp32 device tensor."""
         if q is None:
@@ -380,6 +387,7 @@ class DMC(CodecBase):
     # ------------------------------------------------------------------ public API
     @torch.no_grad()
     def forward_one_frame(self, x, dpb, mv_y_q_scale=None, y_q_scale=None):
+        self._eval_only()
         e = self.engine()
         o = self._run(x, dpb, mv_y_q_scale, y_q_scale, "estimate")
         N, pix = o["N"], o["H"] * o["W"]

@@ -63,6 +63,7 @@ class IntraNoAR(CodecBase):
 
     @torch.no_grad()
     def forward(self, x, q_scale=None):
+        self._eval_only()
         e = self.engine()
         o = self._run(x, q_scale, "estimate")
         pix = o["H"] * o["W"]
