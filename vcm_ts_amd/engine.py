@@ -58,7 +58,9 @@ class View:
 
     def nchw(self) -> torch.Tensor:
         """Zero-copy logical (N, C, H, W) tensor over this view (channels-last strides)."""
-        return self.base[..., self.coff : self.coff + self.C].permute(0, 3, 1, 2)
+        if self.base.dim() == 4 and tuple(self.base.shape) == (self.N, self.H, self.W, self.cs):
+            return self.base[..., self.coff : self.coff + self.C].permute(0, 3, 1, 2)
+        return self.base[:, self.coff : self.coff + self.C]  # alias of a caller's logical-NCHW tensor
 
     @property
     def HW(self):

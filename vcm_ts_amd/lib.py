@@ -33,10 +33,6 @@ def _load(name):
 # ----------------------------------------------------------------------------- rans (host)
 _rans = None
 
-c_i32p = C.POINTER(C.c_int32)
-c_u8p = C.POINTER(C.c_uint8)
-c_f32p = C.POINTER(C.c_float)
-
 
 def rans():
     global _rans
