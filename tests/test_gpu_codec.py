@@ -238,3 +238,29 @@ def test_folder_encode_decode_round_trip(tmp_path):
         a = np.asarray(Image.open(os.path.join(rec_e, f"im{t + 1:05d}.png")))
         b = np.asarray(Image.open(os.path.join(rec_d, f"im{t + 1:05d}.png")))
         assert a.shape == (100, 150, 3) and np.array_equal(a, b)
+
+
+def test_batch_of_rate_points_compress(nets):
+    """Variable-rate encode (BASELINE config 5 / SURVEY 8f-4): N pictures = N rate points through
+    one compress call; each element's stream equals what a batch-1 call at that rate produces and
+    decodes with the ordinary decoder."""
+    d, i = nets
+    h, w = 64, 128
+    fr = frames(31, 2, h, w)
+    x0 = torch.from_numpy(fr[0:1]).cuda()
+    x1 = torch.from_numpy(fr[1:2]).cuda()
+    qs_mv, qs_y = [1.4, 0.8], [1.2, 0.7]
+    ref = i.compress(x0, 1.0)["x_hat"].clone()
+    singles = []
+    for k in range(2):
+        dpb = {"ref_frame": ref.clone(), "ref_feature": None, "ref_y": None, "ref_mv_y": None}
+        singles.append(d.compress(x1, dpb, qs_mv[k], qs_y[k])["bit_stream"])
+    dpb2 = {"ref_frame": torch.cat([ref, ref]), "ref_feature": None, "ref_y": None, "ref_mv_y": None}
+    r = d.compress(torch.cat([x1, x1]), dpb2, torch.tensor(qs_mv).view(2, 1, 1, 1), torch.tensor(qs_y).view(2, 1, 1, 1))
+    assert len(r["bit_streams"]) == 2 and r["bit_stream"] == r["bit_streams"][0]
+    assert r["bit_streams"] == singles and singles[0] != singles[1]
+    rec_batch = r["dpb"]["ref_frame"].clone()
+    for k in range(2):
+        dpb = {"ref_frame": ref.clone(), "ref_feature": None, "ref_y": None, "ref_mv_y": None}
+        dec = d.decompress(dpb, r["bit_streams"][k], h, w, qs_mv[k], qs_y[k])["dpb"]["ref_frame"]
+        assert torch.equal(dec[0], rec_batch[k])

@@ -56,22 +56,36 @@ class PendingStream:
     the launch stream behind the kernels that produce them; finish() waits for them and runs
     the rANS coder.  Lets the caller enqueue the next picture's kernels first (pipeline.py)."""
 
-    def __init__(self, owner, host, event, layout):
-        self.owner, self.host, self.event, self.layout = owner, host, event, layout
-        self._bytes = None
+    def __init__(self, owner, host, event, layout, batch=1):
+        self.owner, self.host, self.event, self.layout, self.batch = owner, host, event, layout, batch
+        self._streams = None
 
-    def finish(self) -> bytes:
-        if self._bytes is None:
+    def finish_all(self):
+        """One payload per batch element: planes are (n, c, y, x) ordered, so element b of every
+        plane is a contiguous slice.  (The reference's coder only handles n = 1; a batch of rate
+        points -- SURVEY 8f-4 -- simply yields one independent stream per element.)"""
+        if self._streams is None:
             self.event.synchronize()
             ec = self.owner.entropy_coder
-            ec.reset_encoder()
             flat = self.host.numpy()
-            for table, s_off, i_off, n, chan in self.layout:
-                cdf, ln, off = self.owner._tables[table]
-                idx = self.owner._chan_index(*chan) if i_off is None else flat[i_off : i_off + n]
-                ec.encode_with_indexes(flat[s_off : s_off + n], idx, cdf, ln, off)
-            self._bytes = ec.flush_encoder()
-        return self._bytes
+            out = []
+            for b in range(self.batch):
+                ec.reset_encoder()
+                for table, s_off, i_off, n, chan in self.layout:
+                    per = n // self.batch
+                    cdf, ln, off = self.owner._tables[table]
+                    lo = s_off + b * per
+                    if i_off is None:
+                        idx = self.owner._chan_index(1, *chan[1:])
+                    else:
+                        idx = flat[i_off + b * per : i_off + (b + 1) * per]
+                    ec.encode_with_indexes(flat[lo : lo + per], idx, cdf, ln, off)
+                out.append(ec.flush_encoder())
+            self._streams = out
+        return self._streams
+
+    def finish(self) -> bytes:
+        return self.finish_all()[0]
 
 
 class CodecBase(nn.Module):
@@ -187,7 +201,7 @@ class CodecBase(nn.Module):
             self._chan_cache[key] = c
         return c
 
-    def _stage_symbols(self, planes) -> PendingStream:
+    def _stage_symbols(self, planes, batch=1) -> PendingStream:
         """planes: list of (table name, sym int32 device tensor, idx int32 device tensor or None,
         (N, C, H, W) for the per-channel index of factorised planes).  One pinned host buffer per
         alternating slot; copies are asynchronous on the current stream."""
@@ -211,7 +225,7 @@ class CodecBase(nn.Module):
             layout.append((table, s_off, i_off, n, chan))
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(self.device))
-        return PendingStream(self, host, ev, layout)
+        return PendingStream(self, host, ev, layout, batch)
 
     def _encode_factorized(self, name, sym: torch.Tensor, N, C_, H, W):
         cdf, ln, off = self._tables[name]
@@ -416,8 +430,7 @@ class DMC(CodecBase):
         if self.entropy_coder is None:
             raise RuntimeError("call update() before compress()/decompress()")
         o = self._run(x, dpb, mv_y_q_scale, y_q_scale, "compress")
-        N = o["N"]
-        assert N == 1, "the bitstream format carries one picture per stream (video_model.py:333-340)"
+        N = o["N"]  # N > 1: a batch of rate points, one independent stream per element ("bit_streams")
         zm, zz = o["mv_z_hat"], o["z_hat"]
         # bitstream order: mv_z, mv_y step 0, mv_y step 1, z, y step 0, y step 1 (video_model.py:333-340)
         pending = self._stage_symbols([
@@ -427,11 +440,12 @@ class DMC(CodecBase):
             ("bit_estimator_z", o["sym_z"], None, (N, 64, zz.H, zz.W)),
             ("scale", o["r_y"]["sym"][0], o["r_y"]["idx"][0], None),
             ("scale", o["r_y"]["sym"][1], o["r_y"]["idx"][1], None),
-        ])
+        ], batch=N)
         d = self._dpb_out(o)
         if defer:
             return {"dbp": d, "dpb": d, "pending": pending, "_views": o}
-        return {"dbp": d, "dpb": d, "bit_stream": pending.finish(), "_views": o}
+        streams = pending.finish_all()
+        return {"dbp": d, "dpb": d, "bit_stream": streams[0], "bit_streams": streams, "_views": o}
 
     @torch.no_grad()
     def decompress(self, dpb, string, height, width, mv_y_q_scale, y_q_scale):
