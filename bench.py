@@ -97,6 +97,7 @@ def main():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--gop", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity-leg", action="store_true", help="skip the extra fp32-mode GOP (N=1 only)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) on a multi-GPU node; gloo to rehearse on one GPU")
     ap.add_argument("--precision", default=os.environ.get("DCVC_PRECISION", "fp16x3"), choices=["fp32", "fp16x3"],
                     help="convolution arithmetic: exact fp32 MFMA or split-fp16 MFMA (3 products, fp32 accumulate)")
@@ -178,6 +179,17 @@ def main():
                    "bits_per_gop": int(bits), "bpp": round(bits / (args.gop * args.height * args.width), 4)},
         "roofline": roofline,
     }
+    if world == 1 and args.precision != "fp32" and not args.no_parity_leg:
+        # the same GOP once in exact-fp32 MFMA mode ("parity mode"), for the record next to `value`
+        del enc
+        i32 = IntraNoAR(precision="fp32").to(dev).eval()
+        p32 = DMC(precision="fp32").to(dev).eval()
+        enc32 = GopEncoder(i32, p32, gop_size=args.gop)
+        enc32.encode_gop(seq[:3], q_i, q_mv, q_y)  # warm-up: weight packing, buffers
+        dt32, bits32 = timed_region(lambda: enc32.encode_gop(seq, q_i, q_mv, q_y)[1], dev)
+        out["parity_mode_fp32"] = {"value": round(args.gop / dt32, 3), "unit": "frames/s", "ms_per_step": round(dt32 * 1e3, 2),
+                                   "bits_per_gop": int(bits32),
+                                   "bits_rel_diff_vs_value_mode": round(abs(bits32 - bits) / max(bits32, 1), 7)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         ph, pw = (args.cpu_size if args.cpu_size else seq[0].shape[-2:])
         cores = host_cores()
