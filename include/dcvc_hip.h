@@ -17,7 +17,7 @@
  *   dcvc_conv_pack_weights  (host) weight re-layout for dcvc_conv2d, run once per layer
  *   dcvc_warp               flow_warp/torch_warp (F.grid_sample bilinear/border/align_corners)
  *                           src/models/video_net.py:32-55
- *   dcvc_up2_flow           bilinearupsacling(flow) * 2.0   video_net.py:58-63,139
+ *   dcvc_up2                bilinearupsacling(flow) * 2.0   video_net.py:58-63,139
  *   dcvc_down2              bilineardownsacling(x) * scale  video_net.py:66-71, video_model.py:237-238
  *                           and F.avg_pool2d(x, 2, 2)       video_net.py:132-133
  *   dcvc_maxpool2           nn.MaxPool2d(2)                 video_net.py:185
@@ -29,9 +29,11 @@
  *                           + GaussianEncoder.build_indexes src/models/common_model.py:82-177,
  *                           src/entropy_models/entropy_models.py:264-268
  *   dcvc_dual_prior_dec_*   CompressionModel.decompress_dual_prior  common_model.py:182-217
- *   dcvc_laplace_bits / dcvc_gaussian_bits / dcvc_factorized_bits / dcvc_sq_err
+ *   dcvc_scale_bits (kind 0 Laplace / 1 Gaussian) / dcvc_factorized_bits / dcvc_sq_err
  *                           get_y_laplace_bits, get_y_gaussian_bits, get_z_bits, probs_to_bits,
  *                           nn.MSELoss + per-sample sums    common_model.py:51-73, video_model.py:538-571
+ *   dcvc_symbols_to_nhwc    decoded symbols back to a float tensor   entropy_models.py:189-195,276-281
+ *   dcvc_copy_channels      the materialised halves of torch.cat where a residual needs them
  */
 #ifndef DCVC_HIP_H
 #define DCVC_HIP_H
