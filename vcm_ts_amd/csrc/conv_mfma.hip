@@ -78,10 +78,10 @@ __device__ __forceinline__ float act(float v, float slope) { return v > 0.f ? v 
 
 #ifdef PROBE_STAMP
 // developer probe: per-workgroup s_memtime stamps of the main-loop phases (tools/conv_stamps.py)
-__device__ unsigned long long *g_stamps;
+__device__ unsigned long long *g_stamps = nullptr;
 #define STAMP(k)                                                                              \
     do {                                                                                      \
-        if (tid == 0 && stamp_i < 62) g_stamps[(size_t)(blockIdx.x + gridDim.x * blockIdx.y) * 64 + 2 + stamp_i++] = \
+        if (tid == 0 && g_stamps && stamp_i < 62) g_stamps[(size_t)(blockIdx.x + gridDim.x * blockIdx.y) * 64 + 2 + stamp_i++] = \
             __builtin_amdgcn_s_memtime();                                                     \
     } while (0)
 #else
@@ -230,7 +230,7 @@ __global__ __launch_bounds__(256, CLASSIC_WAVES_PER_SIMD) void conv_mfma(const C
     Cursor cur = {0, 0, 0, 0};
 #ifdef PROBE_STAMP
     int stamp_i = 0;
-    if (tid == 0) g_stamps[(size_t)(blockIdx.x + gridDim.x * blockIdx.y) * 64] = __builtin_amdgcn_s_memrealtime();
+    if (tid == 0 && g_stamps) g_stamps[(size_t)(blockIdx.x + gridDim.x * blockIdx.y) * 64] = __builtin_amdgcn_s_memrealtime();
 #endif
     STAMP(0);
     load_patch(cur);
@@ -308,7 +308,13 @@ __global__ __launch_bounds__(256, CLASSIC_WAVES_PER_SIMD) void conv_mfma(const C
     }
 
 #ifdef PROBE_NO_EPILOGUE
-    if (a.Hin > 0 && acc[0][0][0] != 12345.678f) return;
+    if (a.Hin > 0 && acc[0][0][0] != 12345.678f) {
+        STAMP(5);
+#ifdef PROBE_STAMP
+        if (tid == 0 && g_stamps) g_stamps[(size_t)(blockIdx.x + gridDim.x * blockIdx.y) * 64 + 1] = __builtin_amdgcn_s_memrealtime();
+#endif
+        return;
+    }
 #endif
     // ---- epilogue: bias, activation, (gated) residual(s), NHWC or pixel-shuffled store.
     const int col = lane & 31, hh = lane >> 5;
@@ -385,7 +391,7 @@ __global__ __launch_bounds__(256, CLASSIC_WAVES_PER_SIMD) void conv_mfma(const C
         }
         STAMP(5);
 #ifdef PROBE_STAMP
-        if (tid == 0) g_stamps[(size_t)(blockIdx.x + gridDim.x * blockIdx.y) * 64 + 1] = __builtin_amdgcn_s_memrealtime();
+        if (tid == 0 && g_stamps) g_stamps[(size_t)(blockIdx.x + gridDim.x * blockIdx.y) * 64 + 1] = __builtin_amdgcn_s_memrealtime();
 #endif
         return;
     }
