@@ -569,9 +569,6 @@ extern "C" int dcvc_conv2d(const dcvc_conv_args *a, void *stream) {
         case 11: return wide ? launch<1, 1, 2, 2>(k, a->N, st, a->precision) : launch<1, 1, 2, 1>(k, a->N, st, a->precision);
         case 12: return wide ? launch<1, 2, 1, 2>(k, a->N, st, a->precision) : launch<1, 2, 1, 1>(k, a->N, st, a->precision);
         case 31:
-#ifdef PROBE_RPW3
-            if (wide && k.Hout >= 96) return launch<3, 1, 3, 2>(k, a->N, st, a->precision);
-#endif
             return wide ? launch<3, 1, 2, 2>(k, a->N, st, a->precision) : launch<3, 1, 2, 1>(k, a->N, st, a->precision);
         case 32: return wide ? launch<3, 2, 1, 2>(k, a->N, st, a->precision) : launch<3, 2, 1, 1>(k, a->N, st, a->precision);
         case 71: return wide ? launch<7, 1, 2, 2>(k, a->N, st, a->precision) : launch<7, 1, 2, 1>(k, a->N, st, a->precision);
