@@ -173,6 +173,16 @@ def test_bitstream_round_trip_and_oracle_decode(nets, tmp_path):
     assert ri["bit"] == os.path.getsize(ipath) * 8 and torch.equal(ri["x_hat"], di["x_hat"])
 
 
+def test_deferred_streams_are_guarded(nets):
+    d, i = nets
+    x = torch.rand(1, 3, 64, 64).cuda()
+    a = i.compress(x, 1.0, defer=True)
+    b = i.compress(x, 1.0, defer=True)
+    with pytest.raises(RuntimeError):  # a third picture would overwrite the first one's pinned planes
+        i.compress(x, 1.0, defer=True)
+    assert a["pending"].finish() == b["pending"].finish() == i.compress(x, 1.0)["bit_stream"]
+
+
 def test_requires_update_and_padding(nets):
     from vcm_ts_amd.dmc import DMC
 

@@ -103,7 +103,7 @@ class CodecBase(nn.Module):
         self.entropy_coder = None
         self._tables = None
         self._flip = 0
-        self._chan_cache, self._stage_bufs, self._stage_flip = {}, {}, 0
+        self._chan_cache, self._stage_bufs, self._stage_flip, self._stage_owner = {}, {}, 0, {}
 
     # -- plumbing ------------------------------------------------------------------------
     def P(self, name):
@@ -208,6 +208,9 @@ class CodecBase(nn.Module):
         total = sum(p[1].numel() + (0 if p[2] is None else p[2].numel()) for p in planes)
         slot = self._stage_flip
         self._stage_flip ^= 1
+        prev = self._stage_owner.get(slot)
+        if prev is not None and prev._streams is None:
+            raise RuntimeError("more than two deferred pictures in flight: call pending.finish() on older ones first")
         key = (slot, total)
         host = self._stage_bufs.get(key)
         if host is None:
@@ -225,7 +228,9 @@ class CodecBase(nn.Module):
             layout.append((table, s_off, i_off, n, chan))
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(self.device))
-        return PendingStream(self, host, ev, layout, batch)
+        pending = PendingStream(self, host, ev, layout, batch)
+        self._stage_owner[slot] = pending
+        return pending
 
     def _encode_factorized(self, name, sym: torch.Tensor, N, C_, H, W):
         cdf, ln, off = self._tables[name]
