@@ -274,3 +274,29 @@ def test_batch_of_rate_points_compress(nets):
         dpb = {"ref_frame": ref.clone(), "ref_feature": None, "ref_y": None, "ref_mv_y": None}
         dec = d.decompress(dpb, r["bit_streams"][k], h, w, qs_mv[k], qs_y[k])["dpb"]["ref_frame"]
         assert torch.equal(dec[0], rec_batch[k])
+
+
+def test_gop_recursion_tracks_oracle(nets):
+    """16 pictures (I + 15 P) through the DPB recursion: every picture's bpp / mse stays within
+    1e-4 of the CPU oracle run on the same inputs (no drift through ref_feature / ref_y / ref_mv_y)."""
+    d, i = nets
+    wd, wi = oracle_weights("dmc"), oracle_weights("intra")
+    n, h, w = 16, 128, 192
+    fr = frames(17, n, h, w)
+    with torch.no_grad():
+        ro = R.intra_forward(wi, torch.from_numpy(fr[0:1]), 1.0)
+        rg = i(torch.from_numpy(fr[0:1]).cuda(), 1.0)
+        _close(rg["bpp"], ro["bpp"].numpy())
+        dpb_o = {"ref_frame": ro["x_hat"], "ref_feature": None, "ref_y": None, "ref_mv_y": None}
+        dpb_g = {"ref_frame": rg["x_hat"], "ref_feature": None, "ref_y": None, "ref_mv_y": None}
+        worst = 0.0
+        for t in range(1, n):
+            x = torch.from_numpy(fr[t : t + 1])
+            po = R.dmc_forward_one_frame(wd, x, dpb_o, 1.0, 1.0)
+            pg = d.forward_one_frame(x.cuda(), dpb_g, 1.0, 1.0)
+            for k in ("bpp", "mse", "bpp_y", "bpp_mv_y"):
+                rel = abs(pg[k].item() - po[k].item()) / abs(po[k].item())
+                worst = max(worst, rel)
+                assert rel < TOL, (t, k, pg[k].item(), po[k].item())
+            dpb_o, dpb_g = po["dpb"], pg["dpb"]
+    print("worst relative deviation over the GOP:", worst)
