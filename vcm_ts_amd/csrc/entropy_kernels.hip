@@ -69,19 +69,21 @@ __global__ void channel_partial(const float *__restrict__ src, int cs, float *__
     }
 }
 
+// grid (N, ceil(C/16)): a block finishes 16 channels with 16 interleaved partial sums each
+// (fixed order, so the result is run-to-run identical).
 __global__ void channel_finish(const float *__restrict__ scratch, float *__restrict__ mean, int HW, int C) {
     __shared__ float sm[256];
     const int n = blockIdx.x, t = threadIdx.x;
-    const int c = t % C, part = t / C, P = 256 / C;  // P interleaved partial sums per channel, fixed order
+    const int c = blockIdx.y * 16 + (t & 15), part = t >> 4;
     float s = 0.f;
-    if (part < P)
-        for (int b = part; b < MB; b += P) s += scratch[((size_t)n * MB + b) * C + c];
+    if (c < C)
+        for (int b = part; b < MB; b += 16) s += scratch[((size_t)n * MB + b) * C + c];
     sm[t] = s;
     __syncthreads();
-    if (t < C) {
+    if (t < 16 && c < C) {
         float r = 0.f;
-        for (int k = 0; k < P; ++k) r += sm[k * C + t];
-        mean[(size_t)n * C + t] = r / (float)HW;
+        for (int k = 0; k < 16; ++k) r += sm[k * 16 + t];
+        mean[(size_t)n * C + c] = r / (float)HW;
     }
 }
 
@@ -304,7 +306,7 @@ extern "C" int dcvc_channel_mean(const float *src, int32_t src_cs, float *mean, 
         return DCVC_E_ARG;
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(channel_partial, dim3(MB, N), dim3(256), 0, st, src, src_cs, scratch, HW, C);
-    hipLaunchKernelGGL(channel_finish, dim3(N), dim3(256), 0, st, scratch, mean, HW, C);
+    hipLaunchKernelGGL(channel_finish, dim3(N, (C + 15) / 16), dim3(256), 0, st, scratch, mean, HW, C);
     RET_LAUNCH();
 }
 
