@@ -307,3 +307,25 @@ def test_gop_recursion_tracks_oracle(nets):
                 assert rel < TOL, (t, k, pg[k].item(), po[k].item())
             dpb_o, dpb_g = po["dpb"], pg["dpb"]
     print("worst relative deviation over the GOP:", worst)
+
+
+def test_escape_coded_symbols_round_trip(nets):
+    """Tiny q-scales blow the latents far outside every CDF table, so most symbols take the
+    sentinel + bypass-nibble path (rans_interface.cpp:105-143 / :217-238) inside the real
+    pipeline; the decoder must still reproduce the encoder's pictures bit for bit."""
+    d, i = nets
+    h, w = 64, 64
+    fr = frames(41, 2, h, w)
+    x0, x1 = torch.from_numpy(fr[0:1]).cuda(), torch.from_numpy(fr[1:2]).cuda()
+    ci = i.compress(x0, 0.01)
+    ysym = ci["_views"]["r"]["sym"][0].cpu().numpy()
+    assert np.abs(ysym).max() > 60  # beyond the widest table (|offset| <= 50): escapes are exercised
+    di = i.decompress(ci["bit_stream"], h, w, 0.01)
+    assert torch.equal(di["x_hat"], ci["x_hat"])
+    dpb = {"ref_frame": di["x_hat"].clone(), "ref_feature": None, "ref_y": None, "ref_mv_y": None}
+    c = d.compress(x1, dpb, 0.01, 0.01)
+    assert np.abs(c["_views"]["r_y"]["sym"][1].cpu().numpy()).max() > 60
+    enc = {k: v.clone() for k, v in c["dpb"].items()}
+    dd = d.decompress(dpb, c["bit_stream"], h, w, 0.01, 0.01)
+    for k in enc:
+        assert torch.equal(dd["dpb"][k], enc[k]), k
