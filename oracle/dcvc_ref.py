@@ -41,9 +41,51 @@ def subpel(w, name, x):
     return F.pixel_shuffle(conv(w, name + ".0", x), 2)
 
 
+class _LowerBound(torch.autograd.Function):
+    """video_net.py:14-28: max(x, bound) whose gradient also passes where it pushes x up."""
+
+    @staticmethod
+    def forward(ctx, inputs, bound):
+        b = torch.ones_like(inputs) * bound
+        ctx.save_for_backward(inputs, b)
+        return torch.max(inputs, b)
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        inputs, b = ctx.saved_tensors
+        passes = (inputs >= b) | (grad_output < 0)
+        return passes.type(grad_output.dtype) * grad_output, None
+
+
 def lower_bound(x, b):
-    """video_net.py:14-19 (forward value only)."""
-    return torch.clamp_min(x, b)
+    return _LowerBound.apply(x, b)
+
+
+_TRAINING = False
+
+
+class training_mode:
+    """with training_mode(): the functions below behave like the reference's modules after
+    .train(): quant() is the straight-through round (common_model.py:38-44) and
+    dmc_forward_one_frame estimates bits on noisy latents (video_model.py:546-550)."""
+
+    def __init__(self, on=True):
+        self.on = on
+
+    def __enter__(self):
+        global _TRAINING
+        self.prev, _TRAINING = _TRAINING, self.on
+
+    def __exit__(self, *a):
+        global _TRAINING
+        _TRAINING = self.prev
+
+
+def quant(x):
+    """CompressionModel.quant (common_model.py:38-44)."""
+    if _TRAINING:
+        return x + (torch.round(x) - x).detach()
+    return torch.round(x)
 
 
 def warp(feature, flow):
@@ -191,10 +233,10 @@ def checker_masks(h, wd):
 
 
 def _masked(y, scales, means, mask):
-    """common_model.py:91-102 with eval-mode quant (round half to even)."""
+    """common_model.py:91-102 (quant: round half to even, straight-through when training)."""
     sh, mh = scales * mask, means * mask
     res = (y - mh) * mask
-    q = torch.round(res)
+    q = quant(res)
     return res, q, q + mh, sh
 
 
@@ -227,7 +269,7 @@ def dual_prior(w, prior_name, y, means, scales, qstep):
 
 def probs_to_bits(p):
     """common_model.py:51-55."""
-    return torch.clamp_min(-1.0 * torch.log(p + 1e-5) / math.log(2.0), 0)
+    return lower_bound(-1.0 * torch.log(p + 1e-5) / math.log(2.0), 0)
 
 
 def laplace_bits(y, sigma):
@@ -423,7 +465,7 @@ def dmc_analysis(w, x, dpb, mv_y_q_scale, y_q_scale):
     o["est_mv"] = spynet(w, x, dpb["ref_frame"])
     mv_y = encoder_stack(w, "mv_encoder", o["est_mv"]) / q_mv
     o["mv_z"] = hyper_enc5(w, "mv_hyper_prior_encoder", mv_y)
-    o["mv_z_hat"] = torch.round(o["mv_z"])
+    o["mv_z_hat"] = quant(o["mv_z"])
     mv_params = hyper_dec(w, "mv_hyper_prior_decoder", o["mv_z_hat"])
     ref_mv_y = dpb.get("ref_mv_y")
     if ref_mv_y is None:
@@ -436,7 +478,7 @@ def dmc_analysis(w, x, dpb, mv_y_q_scale, y_q_scale):
     o["c1"], o["c2"], o["c3"] = c1, c2, c3
     y = contextual_encoder(w, x, c1, c2, c3) / q_y
     o["z"] = three_convs_hyper(w, y)
-    o["z_hat"] = torch.round(o["z"])
+    o["z_hat"] = quant(o["z"])
     hier = hyper_dec(w, "contextual_hyper_prior_decoder", o["z_hat"])
     temporal = conv(w, "temporal_prior_encoder.2", lrelu(conv(w, "temporal_prior_encoder.0", c3, stride=2), 0.1), stride=2)
     ref_y = dpb.get("ref_y")
@@ -458,18 +500,24 @@ def three_convs_hyper(w, y):
     return conv(w, f"{n}.4", t, stride=2)
 
 
-def dmc_forward_one_frame(w, x, dpb, mv_y_q_scale, y_q_scale):
-    """DMC.forward_one_frame in eval mode (video_model.py:470-592)."""
+def dmc_forward_one_frame(w, x, dpb, mv_y_q_scale, y_q_scale, noise=None):
+    """DMC.forward_one_frame (video_model.py:470-592): eval mode, or -- inside training_mode() --
+    the training forward whose add_noise draws (:546-550) are given as noise["y" | "mv_y" | "z" | "mv_z"]."""
     o = dmc_analysis(w, x, dpb, mv_y_q_scale, y_q_scale)
     pix = x.size(2) * x.size(3)
     s = lambda t: torch.sum(t, dim=(1, 2, 3)) / pix
+    if _TRAINING:
+        y_bit, mv_bit = o["y"]["y_res"] + noise["y"], o["mv"]["y_res"] + noise["mv_y"]
+        z_bit, mv_z_bit = o["z"] + noise["z"], o["mv_z"] + noise["mv_z"]
+    else:
+        y_bit, mv_bit, z_bit, mv_z_bit = o["y"]["y_q"], o["mv"]["y_q"], o["z_hat"], o["mv_z_hat"]
     r = {
         "mse": s((x - o["recon"]) ** 2),
         "me_mse": s((x - o["warp_frame"]) ** 2),
-        "bpp_y": s(laplace_bits(o["y"]["y_q"], o["y"]["scales_hat"])),
-        "bpp_mv_y": s(laplace_bits(o["mv"]["y_q"], o["mv"]["scales_hat"])),
-        "bpp_z": s(z_bits(w, "bit_estimator_z", o["z_hat"])),
-        "bpp_mv_z": s(z_bits(w, "bit_estimator_z_mv", o["mv_z_hat"])),
+        "bpp_y": s(laplace_bits(y_bit, o["y"]["scales_hat"])),
+        "bpp_mv_y": s(laplace_bits(mv_bit, o["mv"]["scales_hat"])),
+        "bpp_z": s(z_bits(w, "bit_estimator_z", z_bit)),
+        "bpp_mv_z": s(z_bits(w, "bit_estimator_z_mv", mv_z_bit)),
     }
     r["bpp"] = r["bpp_y"] + r["bpp_z"] + r["bpp_mv_y"] + r["bpp_mv_z"]
     for k in ("", "_y", "_z", "_mv_y", "_mv_z"):

@@ -1,0 +1,964 @@
+// backward.hip -- gradient kernels of the DCVC-HEM P-frame path (include/dcvc_hip_grad.h).
+//
+// The reference gets these from torch.autograd when trainer.py calls loss.backward() on
+// DMC.forward_one_frame's outputs (/root/reference/core/model/dcvc_hem.py:205-229,
+// DCVC_HEM/src/models/video_model.py:470-596).  Here:
+//   * the data gradient of a convolution is the forward MFMA kernel (conv_mfma.hip) run on the
+//     flipped / channel-transposed filter, packed on the device by pack_kernel below;
+//   * the weight gradient is its own MFMA kernel with the pixels as reduction dimension
+//     (wgrad_kernel): C[co][ci] += dY[pixel][co] * X[pixel + tap][ci], fp32 32x32x2 MFMA,
+//     K = 2 neighbouring pixels per instruction, one 32x32 accumulator per filter tap;
+//   * everything else is HBM-bound elementwise / gather / scatter work fused per reference
+//     function (epilogue backward, warp backward, dual-prior backward, likelihood backward).
+// Reductions use fixed-order partial sums; only the scatter kernels (warp / up2 backward) use
+// float atomics, exactly where ATen does.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+
+#include "dcvc_hip_grad.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+#define RET_LAUNCH() return hipGetLastError() == hipSuccess ? DCVC_OK : DCVC_E_LAUNCH
+inline unsigned nblk(int64_t n, int b) { return (unsigned)((n + b - 1) / b); }
+inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+constexpr int KC = 16;               // must match conv_mfma.hip
+constexpr float WGT_SCALE = 64.f;    // must match conv_mfma.hip
+constexpr float F16_MAX = 65504.f;
+
+__device__ __forceinline__ float block_sum(float v, float *sm) {
+    const int t = threadIdx.x;
+    __syncthreads();
+    sm[t] = v;
+    __syncthreads();
+    for (int s = blockDim.x >> 1; s > 0; s >>= 1) {
+        if (t < s) sm[t] += sm[t + s];
+        __syncthreads();
+    }
+    return sm[0];
+}
+
+// ---------------------------------------------------------------------------------------------
+// device-side weight packing
+struct PackK {
+    const float *w;
+    const float *b;
+    float *wpack;
+    float *bpack;
+    int Npk;        // output channels of the packed convolution
+    int cp;         // padded
+    int T, ks;
+    int nseg;
+    int seg_C[DCVC_MAX_SEG], seg_chunk0[DCVC_MAX_SEG], seg_cin0[DCVC_MAX_SEG];
+    int CinT;       // Cin_total of the source tensor
+    int cin_offset;
+    int ps, precision, transposed;
+    int64_t total;  // packed elements (chunks * T * 4 * cp * 4)
+};
+
+__global__ void pack_kernel(const PackK a) {
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid < a.cp) {
+        float bv = 0.f;
+        if (!a.transposed && a.b && gid < a.Npk) {
+            const int np = (int)gid;
+            const int Cq = a.Npk >> 2;
+            const int n = a.ps ? (np % Cq) * 4 + np / Cq : np;
+            bv = a.b[n];
+        }
+        a.bpack[gid] = bv;
+    }
+    if (gid >= a.total) return;
+    const int j = (int)(gid & 3);
+    const int np = (int)((gid >> 2) % a.cp);
+    const int kq = (int)((gid / (4 * (int64_t)a.cp)) & 3);
+    const int t = (int)((gid / (16 * (int64_t)a.cp)) % a.T);
+    const int cg = (int)(gid / (16 * (int64_t)a.cp * a.T));
+    int s = 0;
+    for (int i = 1; i < a.nseg; ++i)
+        if (cg >= a.seg_chunk0[i]) s = i;
+    const int c = (cg - a.seg_chunk0[s]) * KC + kq * 4 + j;
+    float v = 0.f;
+    if (c < a.seg_C[s] && np < a.Npk) {
+        const int Cq = a.Npk >> 2;
+        const int n = a.ps ? (np % Cq) * 4 + np / Cq : np;
+        if (!a.transposed)
+            v = a.w[((size_t)n * a.CinT + a.cin_offset + a.seg_cin0[s] + c) * a.T + t];
+        else  // packed input channel c = forward output channel, packed output n = forward input channel
+            v = a.w[((size_t)c * a.CinT + a.cin_offset + n) * a.T + (a.T - 1 - t)];
+    }
+    if (a.precision == DCVC_PREC_FP32) {
+        a.wpack[gid] = v;
+    } else {
+        const int cc = kq * 4 + j, h = cc >> 3, jj = cc & 7;
+        float sv = v * WGT_SCALE;
+        sv = fminf(fmaxf(sv, -F16_MAX), F16_MAX);
+        const _Float16 hi = (_Float16)sv, lo = (_Float16)(sv - (float)hi);
+        _Float16 *base = (_Float16 *)a.wpack;
+        base[((((size_t)cg * a.T + t) * 4 + h) * a.cp + np) * 8 + jj] = hi;
+        base[((((size_t)cg * a.T + t) * 4 + 2 + h) * a.cp + np) * 8 + jj] = lo;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// epilogue backward
+__global__ void conv_bwd_prologue_kernel(const dcvc_conv_bwd_args a, int64_t total) {
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= total) return;
+    const int c = (int)(gid % a.Cout);
+    const int64_t p = gid / a.Cout;
+    const int ox = (int)(p % a.Wo), oy = (int)((p / a.Wo) % a.Ho);
+    const int64_t n = p / ((int64_t)a.Wo * a.Ho);
+    int cf = c, fy = oy, fx = ox, Hf = a.Ho, Wf = a.Wo, Cfin = a.Cout;
+    if (a.pixel_shuffle) {  // nn.PixelShuffle(2): out[cf][2y+dy][2x+dx] = pre[cf*4 + dy*2 + dx][y][x]
+        cf = c >> 2;
+        fy = 2 * oy + ((c >> 1) & 1);
+        fx = 2 * ox + (c & 1);
+        Hf = 2 * a.Ho;
+        Wf = 2 * a.Wo;
+        Cfin = a.Cout >> 2;
+    }
+    const int64_t fp = (n * Hf + fy) * (int64_t)Wf + fx;
+    float g = a.dout[fp * a.dout_cs + cf];
+    float o = (a.act && a.out) ? a.out[fp * a.out_cs + cf] : 0.f;
+    if (a.res2) {
+        if (a.dres2) a.dres2[fp * a.dres2_cs + cf] += g;
+        if (a.act) o -= a.res2[fp * a.res2_cs + cf];
+    }
+    if (a.res) {
+        const float gt = a.gate ? a.gate[n * Cfin + cf] : 1.f;
+        if (a.dres) a.dres[fp * a.dres_cs + cf] += g * gt;
+        if (a.act) o -= a.res[fp * a.res_cs + cf] * gt;
+    }
+    if (a.act) g *= (o > 0.f) ? 1.f : a.slope;
+    a.dpre[((n * a.Hd + (int64_t)oy * a.zs) * a.Wd + (int64_t)ox * a.zs) * a.dpre_cs + c] = g;
+}
+
+// ---------------------------------------------------------------------------------------------
+// weight gradient
+struct WgradK {
+    const float *x;
+    int x_cs, C, in_act;
+    float in_slope;
+    const float *dpre;
+    int dpre_cs, zs, Hd, Wd;
+    int N, Hin, Win, Ho, Wo, Cout;
+    float *scratch;
+    int nci;        // 32-channel input tiles
+    int ntx, nty;   // spatial tiles
+    int T;
+};
+
+template <int KS, int S>
+__global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradK a) {
+    constexpr int R = 4, TW = S == 1 ? 32 : 16;
+    constexpr int KY = KS == 7 ? 1 : KS;  // filter rows per tap group (7x7: one row per blockIdx.z)
+    constexpr int TG = KY * KS;
+    constexpr int PH = (R - 1) * S + KY, PW = (TW - 1) * S + KS, PAD = KS / 2;
+    constexpr int XS = PH * PW * 32 > 4096 ? PH * PW * 32 : 4096;
+    __shared__ __attribute__((aligned(16))) float dys[R * TW * 32];
+    __shared__ __attribute__((aligned(16))) float xs[XS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int col = lane & 31, hh = lane >> 5;
+    const int cot = blockIdx.y / a.nci, cit = blockIdx.y % a.nci;
+    const int co0 = cot * 32, ci0 = cit * 32;
+    const int grp = blockIdx.z;  // filter row for 7x7, 0 otherwise
+    const int ky0 = KS == 7 ? grp : 0;
+
+    f32x16 acc[TG];
+#pragma unroll
+    for (int t = 0; t < TG; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    const int ntiles = a.N * a.nty * a.ntx;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int tx = tile % a.ntx, ty = (tile / a.ntx) % a.nty, n = tile / (a.ntx * a.nty);
+        __syncthreads();
+        // dY tile: R x TW pixels x 32 output channels
+        for (int i = tid; i < R * TW * 8; i += 256) {
+            const int p = i >> 3, q = i & 7;
+            const int r = p / TW, xx = p - r * TW;
+            const int oy = ty * R + r, ox = tx * TW + xx;
+            const int c = co0 + q * 4;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (oy < a.Ho && ox < a.Wo && c < a.Cout) {
+                const float *src = a.dpre + (((size_t)n * a.Hd + (size_t)oy * a.zs) * a.Wd + (size_t)ox * a.zs) * a.dpre_cs + c;
+                v[0] = src[0];
+                if (c + 1 < a.Cout) v[1] = src[1];
+                if (c + 2 < a.Cout) v[2] = src[2];
+                if (c + 3 < a.Cout) v[3] = src[3];
+            }
+            *(f32x4 *)&dys[p * 32 + q * 4] = v;
+        }
+        // input patch: PH x PW pixels x 32 input channels
+        const int gy0 = ty * R * S - PAD + ky0, gx0 = tx * TW * S - PAD;
+        for (int i = tid; i < PH * PW * 8; i += 256) {
+            const int p = i >> 3, q = i & 7;
+            const int py = p / PW, px = p - py * PW;
+            const int gy = gy0 + py, gx = gx0 + px;
+            const int c = ci0 + q * 4;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (gy >= 0 && gy < a.Hin && gx >= 0 && gx < a.Win && c < a.C) {
+                const float *src = a.x + (((size_t)n * a.Hin + gy) * a.Win + gx) * a.x_cs + c;
+                v[0] = src[0];
+                if (c + 1 < a.C) v[1] = src[1];
+                if (c + 2 < a.C) v[2] = src[2];
+                if (c + 3 < a.C) v[3] = src[3];
+                if (a.in_act) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * a.in_slope;
+                }
+            }
+            *(f32x4 *)&xs[p * 32 + q * 4] = v;
+        }
+        __syncthreads();
+        const int r = wave;  // one output row of the tile per wave
+#pragma unroll 4
+        for (int xp = 0; xp < TW; xp += 2) {
+            const float av = dys[(r * TW + xp + hh) * 32 + col];
+#pragma unroll
+            for (int t = 0; t < TG; ++t) {
+                const int ky = t / KS, kx = t - ky * KS;
+                const float bv = xs[((r * S + ky) * PW + (xp + hh) * S + kx) * 32 + col];
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t], 0, 0, 0);
+            }
+        }
+    }
+    // cross-wave reduction, one tap at a time, then the block's partial goes to scratch
+    const int nct = gridDim.y;
+#pragma unroll
+    for (int t = 0; t < TG; ++t) {
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) xs[wave * 1024 + ((r & 3) + 8 * (r >> 2) + 4 * hh) * 32 + col] = acc[t][r];
+        __syncthreads();
+        float *dst = a.scratch + (((size_t)blockIdx.x * nct + blockIdx.y) * a.T + (grp * TG + t)) * 1024;
+        for (int i = tid; i < 1024; i += 256) dst[i] = (xs[i] + xs[1024 + i]) + (xs[2048 + i] + xs[3072 + i]);
+    }
+}
+
+__global__ void wgrad_reduce_kernel(const float *__restrict__ scratch, float *__restrict__ dw, int splits, int nct,
+                                    int nci, int T, int Cout, int C, int CinT, int cin_offset) {
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (int64_t)Cout * C * T) return;
+    const int t = (int)(gid % T);
+    const int ci = (int)((gid / T) % C);
+    const int co = (int)(gid / ((int64_t)T * C));
+    const int tile = (co >> 5) * nci + (ci >> 5);
+    const int e = (co & 31) * 32 + (ci & 31);
+    float s = 0.f;
+    for (int k = 0; k < splits; ++k) s += scratch[(((size_t)k * nct + tile) * T + t) * 1024 + e];
+    dw[((size_t)co * CinT + cin_offset + ci) * T + t] += s;
+}
+
+// ---------------------------------------------------------------------------------------------
+// per-channel dot products
+__global__ void channel_dot_partial(const float *__restrict__ a, int a_cs, const float *__restrict__ b, int b_cs,
+                                    float *__restrict__ scratch, int HW, int C, int NB) {
+    __shared__ float sm[256];
+    const int n = blockIdx.y, blk = blockIdx.x, t = threadIdx.x;
+    const int cb = blockIdx.z * 256;
+    const int Cl = min(C - cb, 256);
+    const int G = 256 / Cl;
+    const int cl = t % Cl, g = t / Cl;
+    const int per = (HW + NB - 1) / NB;
+    const int p0 = blk * per, p1 = min(HW, p0 + per);
+    float v = 0.f;
+    if (g < G)
+        for (int p = p0 + g; p < p1; p += G) {
+            const size_t pix = (size_t)n * HW + p;
+            const float av = a[pix * a_cs + cb + cl];
+            v += b ? av * b[pix * b_cs + cb + cl] : av;
+        }
+    sm[t] = v;
+    __syncthreads();
+    if (t < Cl) {
+        float s = 0.f;
+        for (int k = 0; k < G; ++k) s += sm[k * Cl + t];
+        scratch[((size_t)n * NB + blk) * C + cb + t] = s;
+    }
+}
+
+__global__ void channel_dot_finish(const float *__restrict__ scratch, float *__restrict__ out, int N, int C, int NB,
+                                   int over_batch, int accumulate) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    if (over_batch) {
+        float s = 0.f;
+        for (int n = 0; n < N; ++n)
+            for (int k = 0; k < NB; ++k) s += scratch[((size_t)n * NB + k) * C + c];
+        out[c] = accumulate ? out[c] + s : s;
+    } else {
+        const int n = blockIdx.y;
+        float s = 0.f;
+        for (int k = 0; k < NB; ++k) s += scratch[((size_t)n * NB + k) * C + c];
+        out[(size_t)n * C + c] = accumulate ? out[(size_t)n * C + c] + s : s;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// elementwise
+__global__ void mask_accumulate_kernel(const float *__restrict__ src, int src_cs, const float *__restrict__ x, int x_cs,
+                                       float slope, float *__restrict__ dst, int dst_cs, int64_t npix, int C) {
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= npix * C) return;
+    const int c = (int)(gid % C);
+    const int64_t p = gid / C;
+    float v = src[p * src_cs + c];
+    if (x) v *= x[p * x_cs + c] > 0.f ? 1.f : slope;
+    dst[p * dst_cs + c] += v;
+}
+
+__global__ void add_planes_kernel(const float *__restrict__ a, int a_cs, const float *__restrict__ b, int b_cs,
+                                  float *__restrict__ out, int out_cs, int64_t npix, int C) {
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= npix * C) return;
+    const int c = (int)(gid % C);
+    const int64_t p = gid / C;
+    out[p * out_cs + c] = a[p * a_cs + c] + b[p * b_cs + c];
+}
+
+__global__ void add_channel_vec_kernel(float *__restrict__ dst, int dst_cs, const float *__restrict__ vec, float scale,
+                                       int64_t HW, int C, int64_t total) {
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= total) return;
+    const int c = (int)(gid % C);
+    const int64_t p = gid / C;
+    const int64_t n = p / HW;
+    dst[p * dst_cs + c] += vec[n * C + c] * scale;
+}
+
+// ---------------------------------------------------------------------------------------------
+// resampling backward.  Coordinates are rebuilt exactly as in resample.hip (make_tap).
+__device__ __forceinline__ float lin11(int i, int n) {
+    const float step = 2.0f / (float)(n - 1);
+    return i < n / 2 ? -1.0f + step * (float)i : 1.0f - step * (float)(n - 1 - i);
+}
+
+// One thread per (pixel, channel): scatter into dsrc with atomics, reduce the flow gradient
+// over the channels of a pixel through LDS (a block holds whole pixels: 256 % Cl == 0 or Cl == C loop).
+__global__ void warp_bwd_kernel(const float *__restrict__ src, int src_cs, const float *__restrict__ flow, int flow_cs,
+                                const float *__restrict__ dout, int dout_cs, float *__restrict__ dsrc, int dsrc_cs,
+                                float *__restrict__ dflow, int dflow_cs, int N, int H, int W, int C) {
+    const int64_t pix = (int64_t)blockIdx.x * blockDim.y + threadIdx.y;  // blockDim = (Cl, 256 / Cl)
+    const bool live = pix < (int64_t)N * H * W;
+    float gx_acc = 0.f, gy_acc = 0.f;
+    if (live) {
+        const int x = (int)(pix % W), y = (int)((pix / W) % H);
+        const int64_t n = pix / ((int64_t)W * H);
+        const float fx = flow[pix * flow_cs], fy = flow[pix * flow_cs + 1];
+        const float hx = (float)(((double)W - 1.0) / 2.0), hy = (float)(((double)H - 1.0) / 2.0);
+        float ix = (lin11(x, W) + fx / hx + 1.0f) * hx, iy = (lin11(y, H) + fy / hy + 1.0f) * hy;
+        // clip_coordinates_set_grad: zero gradient at and beyond the border
+        const float mx = (ix <= 0.f || ix >= (float)(W - 1)) ? 0.f : 1.f;
+        const float my = (iy <= 0.f || iy >= (float)(H - 1)) ? 0.f : 1.f;
+        ix = fminf((float)(W - 1), fmaxf(ix, 0.0f));
+        iy = fminf((float)(H - 1), fmaxf(iy, 0.0f));
+        const float xw = floorf(ix), yn = floorf(iy);
+        const float w = ix - xw, e = 1.0f - w, nn = iy - yn, s = 1.0f - nn;
+        const int x0 = (int)xw, y0 = (int)yn, x1 = min(x0 + 1, W - 1), y1 = min(y0 + 1, H - 1);
+        const bool x1in = x0 + 1 <= W - 1, y1in = y0 + 1 <= H - 1;  // ATen drops out-of-range taps
+        const size_t b = (size_t)n * H * W;
+        const size_t pnw = b + (size_t)y0 * W + x0, pne = b + (size_t)y0 * W + x1;
+        const size_t psw = b + (size_t)y1 * W + x0, pse = b + (size_t)y1 * W + x1;
+        for (int c = threadIdx.x; c < C; c += blockDim.x) {
+            const float g = dout[pix * dout_cs + c];
+            const float vnw = src[pnw * src_cs + c];
+            const float vne = x1in ? src[pne * src_cs + c] : 0.f;
+            const float vsw = y1in ? src[psw * src_cs + c] : 0.f;
+            const float vse = (x1in && y1in) ? src[pse * src_cs + c] : 0.f;
+            gx_acc += g * (s * (vne - vnw) + nn * (vse - vsw));
+            gy_acc += g * (e * (vsw - vnw) + w * (vse - vne));
+            if (dsrc) {
+                atomicAdd(&dsrc[pnw * dsrc_cs + c], g * (s * e));
+                if (x1in) atomicAdd(&dsrc[pne * dsrc_cs + c], g * (s * w));
+                if (y1in) atomicAdd(&dsrc[psw * dsrc_cs + c], g * (nn * e));
+                if (x1in && y1in) atomicAdd(&dsrc[pse * dsrc_cs + c], g * (nn * w));
+            }
+        }
+        gx_acc *= mx;
+        gy_acc *= my;
+    }
+    if (!dflow) return;
+    __shared__ float sx[256], sy[256];
+    const int t = threadIdx.y * blockDim.x + threadIdx.x;
+    sx[t] = gx_acc;
+    sy[t] = gy_acc;
+    __syncthreads();
+    if (threadIdx.x == 0 && live) {
+        float ax = 0.f, ay = 0.f;
+        for (int k = 0; k < (int)blockDim.x; ++k) {
+            ax += sx[t + k];
+            ay += sy[t + k];
+        }
+        dflow[pix * dflow_cs] += ax;
+        dflow[pix * dflow_cs + 1] += ay;
+    }
+}
+
+__global__ void up2_bwd_kernel(const float *__restrict__ dout, int dout_cs, float *__restrict__ dsrc, int dsrc_cs, int N,
+                               int H, int W, int C, float scale) {
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int Ho = 2 * H, Wo = 2 * W;
+    if (gid >= (int64_t)N * Ho * Wo * C) return;
+    const int c = (int)(gid % C);
+    const int64_t pix = gid / C;
+    const int ox = (int)(pix % Wo), oy = (int)((pix / Wo) % Ho);
+    const int64_t n = pix / ((int64_t)Wo * Ho);
+    const float sx = fmaxf(((float)ox + 0.5f) * 0.5f - 0.5f, 0.f), sy = fmaxf(((float)oy + 0.5f) * 0.5f - 0.5f, 0.f);
+    const int x0 = (int)sx, y0 = (int)sy;
+    const int x1 = min(x0 + 1, W - 1), y1 = min(y0 + 1, H - 1);
+    const float lx1 = sx - (float)x0, lx0 = 1.f - lx1, ly1 = sy - (float)y0, ly0 = 1.f - ly1;
+    const float g = dout[pix * dout_cs + c] * scale;
+    float *b = dsrc + n * (int64_t)H * W * dsrc_cs + c;
+    atomicAdd(&b[((int64_t)y0 * W + x0) * dsrc_cs], g * ly0 * lx0);
+    atomicAdd(&b[((int64_t)y0 * W + x1) * dsrc_cs], g * ly0 * lx1);
+    atomicAdd(&b[((int64_t)y1 * W + x0) * dsrc_cs], g * ly1 * lx0);
+    atomicAdd(&b[((int64_t)y1 * W + x1) * dsrc_cs], g * ly1 * lx1);
+}
+
+__global__ void down2_bwd_kernel(const float *__restrict__ dout, int dout_cs, float *__restrict__ dsrc, int dsrc_cs,
+                                 int N, int H, int W, int C, float k) {
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (int64_t)N * H * W * C) return;
+    const int c = (int)(gid % C);
+    const int64_t pix = gid / C;
+    const int x = (int)(pix % W), y = (int)((pix / W) % H);
+    const int64_t n = pix / ((int64_t)W * H);
+    const int64_t op = (n * (H / 2) + y / 2) * (int64_t)(W / 2) + x / 2;
+    dsrc[pix * dsrc_cs + c] += dout[op * dout_cs + c] * k;
+}
+
+__global__ void maxpool2_bwd_kernel(const float *__restrict__ src, int src_cs, const float *__restrict__ dout,
+                                    int dout_cs, float *__restrict__ dsrc, int dsrc_cs, int N, int H, int W, int C) {
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int Ho = H / 2, Wo = W / 2;
+    if (gid >= (int64_t)N * Ho * Wo * C) return;
+    const int c = (int)(gid % C);
+    const int64_t pix = gid / C;
+    const int ox = (int)(pix % Wo), oy = (int)((pix / Wo) % Ho);
+    const int64_t n = pix / ((int64_t)Wo * Ho);
+    const int64_t p00 = (n * H + 2 * oy) * (int64_t)W + 2 * ox;
+    const int64_t cand[4] = {p00, p00 + 1, p00 + W, p00 + W + 1};
+    int best = 0;
+    float bv = src[cand[0] * src_cs + c];
+#pragma unroll
+    for (int k = 1; k < 4; ++k) {
+        const float v = src[cand[k] * src_cs + c];
+        if (v > bv || v != v) {
+            bv = v;
+            best = k;
+        }
+    }
+    dsrc[cand[best] * dsrc_cs + c] += dout[pix * dout_cs + c];
+}
+
+// ---------------------------------------------------------------------------------------------
+// SE layer FC part: one block, all samples
+__global__ void se_bwd_kernel(const float *__restrict__ mean, const float *__restrict__ w1, const float *__restrict__ w2,
+                              const float *__restrict__ gate, const float *__restrict__ dgate, float *__restrict__ dmean,
+                              float *__restrict__ dw1, float *__restrict__ dw2, int N, int C, int Cr) {
+    __shared__ float hid[64], dhid[64], ds[256];
+    const int t = threadIdx.x;
+    for (int n = 0; n < N; ++n) {
+        __syncthreads();
+        if (t < Cr) {
+            float s = 0.f;
+            for (int c = 0; c < C; ++c) s += w1[t * C + c] * mean[(size_t)n * C + c];
+            hid[t] = fmaxf(s, 0.f);
+        }
+        if (t < C) {
+            const float g = gate[(size_t)n * C + t];
+            ds[t] = dgate[(size_t)n * C + t] * g * (1.f - g);
+        }
+        __syncthreads();
+        if (t < Cr) {
+            float s = 0.f;
+            for (int c = 0; c < C; ++c) s += w2[c * Cr + t] * ds[c];
+            dhid[t] = hid[t] > 0.f ? s : 0.f;
+        }
+        if (t < C && dw2)
+            for (int j = 0; j < Cr; ++j) dw2[t * Cr + j] += ds[t] * hid[j];
+        __syncthreads();
+        if (t < C) {
+            float s = 0.f;
+            for (int j = 0; j < Cr; ++j) s += w1[j * C + t] * dhid[j];
+            dmean[(size_t)n * C + t] = s;
+            if (dw1)
+                for (int j = 0; j < Cr; ++j) dw1[j * C + t] += dhid[j] * mean[(size_t)n * C + t];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// q scales
+__global__ void scale_channels_bwd_kernel(const float *__restrict__ dout, int dout_cs, float *__restrict__ dsrc,
+                                          int dsrc_cs, const float *__restrict__ q_basic,
+                                          const float *__restrict__ q_scale, int mode, int64_t HW, int C, int64_t total) {
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= total) return;
+    const int c = (int)(gid % C);
+    const int64_t pix = gid / C;
+    const int n = (int)(pix / HW);
+    const float q = fmaxf(q_basic[c], 0.5f) * q_scale[n];
+    const float g = dout[pix * dout_cs + c];
+    dsrc[pix * dsrc_cs + c] += mode ? g * q : g / q;
+}
+
+__global__ void q_finish_kernel(const float *__restrict__ dq_mul, const float *__restrict__ s_div,
+                                const float *__restrict__ q_basic, const float *__restrict__ q_scale,
+                                float *__restrict__ dq_basic, float *__restrict__ dq_scale, int N, int C) {
+    __shared__ float sm[256];
+    const int t = threadIdx.x;
+    // per-channel: sum over samples
+    for (int c0 = 0; c0 < C; c0 += 256) {
+        const int c = c0 + t;
+        if (c < C && dq_basic) {
+            const float qb = fmaxf(q_basic[c], 0.5f);
+            float s = 0.f;
+            for (int n = 0; n < N; ++n) {
+                float d = dq_mul ? dq_mul[(size_t)n * C + c] : 0.f;
+                if (s_div) d -= s_div[(size_t)n * C + c] / (qb * q_scale[n]);
+                s += d * q_scale[n];
+            }
+            if (q_basic[c] >= 0.5f || s < 0.f) dq_basic[c] += s;
+        }
+    }
+    if (!dq_scale) return;
+    for (int n = 0; n < N; ++n) {
+        float v = 0.f;
+        for (int c = t; c < C; c += 256) {
+            const float qb = fmaxf(q_basic[c], 0.5f);
+            float d = dq_mul ? dq_mul[(size_t)n * C + c] : 0.f;
+            if (s_div) d -= s_div[(size_t)n * C + c] / (qb * q_scale[n]);
+            v += d * qb;
+        }
+        const float s = block_sum(v, sm);
+        if (t == 0) dq_scale[n] += s;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// dual prior
+__global__ void dual_prior_bwd_kernel(const dcvc_dual_prior_bwd_args a, int64_t total) {
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= total) return;
+    const int C = a.C, Ch = C >> 1;
+    const int c = (int)(gid % C);
+    const int64_t pix = gid / C;
+    const int x = (int)(pix % a.W), y = (int)((pix / a.W) % a.H);
+    const int64_t n = pix / ((int64_t)a.W * a.H);
+    const bool half = c >= Ch;
+    const int k = half ? c - Ch : c;
+    const bool m0 = ((x + y) & 1) == 0;
+    const bool active0 = half ? !m0 : m0;
+    const int64_t e = pix * C + c;
+    const float dres = a.dy_res ? a.dy_res[e] : 0.f;
+    const float dsh = a.dscales_hat ? a.dscales_hat[e] : 0.f;
+    if (a.step == 1) {
+        float *ds = a.dspatial + pix * a.dspatial_cs;
+        ds[half ? C + k : k] = active0 ? 0.f : dsh;
+        ds[half ? C + Ch + k : Ch + k] = active0 ? 0.f : -dres;
+        return;
+    }
+    const float *fu = a.fusion + pix * a.fusion_cs;
+    const float qs = fmaxf(fu[c], 0.5f);
+    const float cq = fmaxf(a.q_basic[c], 0.5f) * a.q_scale[n];
+    const float hat = a.y_hat[e];
+    const float g_out = a.dout ? a.dout[pix * a.dout_cs + c] : 0.f;
+    const float *dp = a.dparams ? a.dparams + pix * a.dparams_cs : nullptr;
+    float g_hat = g_out * qs * cq;
+    if (active0 && dp) g_hat += dp[c];
+    const float g_yq = g_hat + dres;
+    float g_sc = active0 ? dsh : 0.f, g_mu = active0 ? -dres : 0.f, g_qs = 0.f;
+    if (dp) {
+        g_mu += dp[C + c];
+        g_sc += dp[2 * C + c];
+        g_qs += dp[3 * C + c];
+    }
+    const float yv = a.y[pix * a.y_cs + c];
+    const float yq = yv / qs;
+    g_qs += g_out * hat * cq - g_yq * yq / qs;
+    float *df = a.dfusion + pix * a.dfusion_cs;
+    if (fu[c] >= 0.5f || g_qs < 0.f) df[c] += g_qs;
+    df[C + c] += g_sc;
+    df[2 * C + c] += g_mu;
+    if (a.dy) a.dy[pix * a.dy_cs + c] += g_yq / qs;
+    if (a.dq_plane) a.dq_plane[e] = g_out * hat * qs;
+}
+
+// ---------------------------------------------------------------------------------------------
+// likelihoods
+__device__ __forceinline__ float sgn(float v) { return (float)((v > 0.f) - (v < 0.f)); }
+
+__global__ void scale_bits_bwd_kernel(const float *__restrict__ yv, const float *__restrict__ sh, const float *__restrict__ g,
+                                      float *__restrict__ dy, float *__restrict__ dsc, int64_t per, int64_t total) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const float up = g[i / per];
+    const float y = yv[i], s_raw = sh[i];
+    const float b = fminf(fmaxf(s_raw, 1e-5f), 1e10f);
+    const float t1 = y + 0.5f, t0 = y - 0.5f;
+    const float s1 = sgn(t1), s0 = sgn(t0);
+    const float e1 = expf(-fabsf(t1) / b), e0 = expf(-fabsf(t0) / b);
+    const float F1 = 0.5f - 0.5f * s1 * expm1f(-fabsf(t1) / b), F0 = 0.5f - 0.5f * s0 * expm1f(-fabsf(t0) / b);
+    const float p = F1 - F0;
+    const float bits = (-1.0f * logf(p + 1e-5f)) / 0.6931471805599453f;
+    float gb = (bits >= 0.f || up < 0.f) ? up : 0.f;          // LowerBound(bits, 0) backward
+    const float gp = -gb / ((p + 1e-5f) * 0.6931471805599453f);
+    // dF/dt = 0.5 sign(t)^2 exp(-|t|/b) / b ;  dF/db = -0.5 sign(t) exp(-|t|/b) |t| / b^2
+    const float dFdt1 = 0.5f * s1 * s1 * e1 / b, dFdt0 = 0.5f * s0 * s0 * e0 / b;
+    const float dFdb1 = -0.5f * s1 * e1 * fabsf(t1) / (b * b), dFdb0 = -0.5f * s0 * e0 * fabsf(t0) / (b * b);
+    dy[i] = gp * (dFdt1 - dFdt0);
+    const bool inside = s_raw >= 1e-5f && s_raw <= 1e10f;      // clamp passes the gradient inside its range
+    dsc[i] = inside ? gp * (dFdb1 - dFdb0) : 0.f;
+}
+
+__device__ __forceinline__ float softplusf(float x) { return x > 20.f ? x : log1pf(expf(x)); }
+__device__ __forceinline__ float sigmoidf(float x) { return 1.f / (1.f + expf(-x)); }
+
+// forward of the 4-layer per-channel CDF keeping what the backward needs; returns sigmoid(logit)
+struct FactState {
+    float xin[4], x1[3];  // layer inputs, pre-tanh values
+};
+__device__ __forceinline__ float fact_fwd(float x, const float *P, FactState &st) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        st.xin[i] = x;
+        const float v = x * softplusf(P[3 * i]) + P[3 * i + 1];
+        st.x1[i] = v;
+        x = v + tanhf(v) * tanhf(P[3 * i + 2]);
+    }
+    st.xin[3] = x;
+    x = x * softplusf(P[9]) + P[10];
+    return sigmoidf(x);
+}
+// adds d(cdf)/d(params) * gcdf into dP[11] and returns d(cdf)/dx * gcdf
+__device__ __forceinline__ float fact_bwd(float cdf, float gcdf, const float *P, const FactState &st, float *dP) {
+    float gx = gcdf * cdf * (1.f - cdf);  // through the sigmoid
+    dP[10] += gx;
+    dP[9] += gx * st.xin[3] * sigmoidf(P[9]);
+    gx *= softplusf(P[9]);
+#pragma unroll
+    for (int i = 2; i >= 0; --i) {
+        const float th = tanhf(st.x1[i]), ta = tanhf(P[3 * i + 2]);
+        dP[3 * i + 2] += gx * th * (1.f - ta * ta);
+        const float gv = gx * (1.f + (1.f - th * th) * ta);
+        dP[3 * i + 1] += gv;
+        dP[3 * i] += gv * st.xin[i] * sigmoidf(P[3 * i]);
+        gx = gv * softplusf(P[3 * i]);
+    }
+    return gx;
+}
+
+// one block per channel; loops over all samples / pixels of the channel
+__global__ void factorized_bits_bwd_kernel(const float *__restrict__ z, int z_cs, const float *__restrict__ P,
+                                           const float *__restrict__ g, float *__restrict__ dz, int dz_cs,
+                                           float *__restrict__ dparams, int N, int64_t HW, int C) {
+    __shared__ float sm[256];
+    const int c = blockIdx.x;
+    float Pc[11], dP[11];
+#pragma unroll
+    for (int i = 0; i < 11; ++i) {
+        Pc[i] = P[i * C + c];
+        dP[i] = 0.f;
+    }
+    const int64_t total = (int64_t)N * HW;
+    for (int64_t i = threadIdx.x; i < total; i += 256) {
+        const float up = g[i / HW];
+        const float zz = z[i * z_cs + c];
+        FactState s1, s0;
+        const float c1 = fact_fwd(zz + 0.5f, Pc, s1), c0 = fact_fwd(zz - 0.5f, Pc, s0);
+        const float p = c1 - c0;
+        const float bits = (-1.0f * logf(p + 1e-5f)) / 0.6931471805599453f;
+        const float gb = (bits >= 0.f || up < 0.f) ? up : 0.f;
+        const float gp = -gb / ((p + 1e-5f) * 0.6931471805599453f);
+        const float gz = fact_bwd(c1, gp, Pc, s1, dP) + fact_bwd(c0, -gp, Pc, s0, dP);
+        if (dz) dz[i * dz_cs + c] += gz;
+    }
+    if (!dparams) return;
+    for (int i = 0; i < 11; ++i) {
+        const float s = block_sum(dP[i], sm);
+        if (threadIdx.x == 0) dparams[i * C + c] += s;
+    }
+}
+
+__global__ void sq_err_bwd_kernel(const float *__restrict__ a, int a_cs, const float *__restrict__ b, int b_cs,
+                                  const float *__restrict__ g, float *__restrict__ da, int da_cs, int64_t HW, int C,
+                                  int64_t total) {
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= total) return;
+    const int c = (int)(gid % C);
+    const int64_t pix = gid / C;
+    const int64_t n = pix / HW;
+    da[pix * da_cs + c] += 2.f * (a[pix * a_cs + c] - b[pix * b_cs + c]) * g[n];
+}
+
+}  // namespace
+
+// =============================================================================================
+extern "C" int dcvc_conv_pack_weights_dev(const float *w, const float *b, int32_t Cout, int32_t Cin_total, int32_t ks,
+                                          int32_t nseg, const int32_t *seg_C, int32_t cin_offset, int32_t pixel_shuffle,
+                                          int32_t precision, int32_t transposed, float *wpack, float *bpack,
+                                          void *stream) {
+    if (!w || !wpack || !bpack || !seg_C || nseg < 1 || nseg > DCVC_MAX_SEG || (ks != 1 && ks != 3 && ks != 7))
+        return DCVC_E_ARG;
+    if (precision != DCVC_PREC_FP32 && precision != DCVC_PREC_FP16X3) return DCVC_E_ARG;
+    if (transposed && (nseg != 1 || pixel_shuffle)) return DCVC_E_ARG;
+    PackK k;
+    memset(&k, 0, sizeof(k));
+    k.w = w;
+    k.b = b;
+    k.wpack = wpack;
+    k.bpack = bpack;
+    k.T = ks * ks;
+    k.ks = ks;
+    k.CinT = Cin_total;
+    k.cin_offset = cin_offset;
+    k.ps = pixel_shuffle;
+    k.precision = precision;
+    k.transposed = transposed;
+    int chunks = 0, cin0 = 0;
+    if (!transposed) {
+        k.Npk = Cout;
+        k.nseg = nseg;
+        for (int s = 0; s < nseg; ++s) {
+            if (seg_C[s] <= 0) return DCVC_E_ARG;
+            k.seg_C[s] = seg_C[s];
+            k.seg_chunk0[s] = chunks;
+            k.seg_cin0[s] = cin0;
+            chunks += (seg_C[s] + KC - 1) / KC;
+            cin0 += seg_C[s];
+        }
+        if (cin_offset < 0 || cin_offset + cin0 > Cin_total) return DCVC_E_ARG;
+    } else {
+        if (seg_C[0] <= 0 || cin_offset < 0 || cin_offset + seg_C[0] > Cin_total) return DCVC_E_ARG;
+        k.Npk = seg_C[0];
+        k.nseg = 1;
+        k.seg_C[0] = Cout;
+        chunks = (Cout + KC - 1) / KC;
+    }
+    if (pixel_shuffle && (k.Npk & 3)) return DCVC_E_ARG;
+    k.cp = round_up(k.Npk, 32);
+    k.total = (int64_t)chunks * k.T * 4 * k.cp * 4;
+    hipLaunchKernelGGL(pack_kernel, dim3(nblk(k.total, 256)), dim3(256), 0, (hipStream_t)stream, k);
+    RET_LAUNCH();
+}
+
+extern "C" int dcvc_conv_bwd_prologue(const dcvc_conv_bwd_args *a, void *stream) {
+    if (!a || !a->dout || !a->dpre || a->N <= 0 || a->Ho <= 0 || a->Wo <= 0 || a->Cout <= 0 || a->zs < 1) return DCVC_E_ARG;
+    if (a->act && !a->out) return DCVC_E_ARG;
+    if (a->pixel_shuffle && (a->Cout & 3)) return DCVC_E_ARG;
+    if ((a->Ho - 1) * a->zs >= a->Hd || (a->Wo - 1) * a->zs >= a->Wd || a->dpre_cs < a->Cout) return DCVC_E_ARG;
+    const int64_t total = (int64_t)a->N * a->Ho * a->Wo * a->Cout;
+    hipLaunchKernelGGL(conv_bwd_prologue_kernel, dim3(nblk(total, 256)), dim3(256), 0, (hipStream_t)stream, *a, total);
+    RET_LAUNCH();
+}
+
+extern "C" int64_t dcvc_conv_wgrad_scratch_min(int32_t Cout, int32_t C, int32_t ks) {
+    if (Cout <= 0 || C <= 0 || (ks != 1 && ks != 3 && ks != 7)) return DCVC_E_ARG;
+    return (int64_t)((Cout + 31) / 32) * ((C + 31) / 32) * ks * ks * 1024;
+}
+
+extern "C" int dcvc_conv_wgrad(const dcvc_conv_wgrad_args *a, void *stream) {
+    if (!a || !a->x || !a->dpre || !a->dw || !a->scratch || a->N <= 0 || a->C <= 0 || a->Cout <= 0) return DCVC_E_ARG;
+    if ((a->ks != 1 && a->ks != 3 && a->ks != 7) || (a->stride != 1 && a->stride != 2) || (a->ks == 7 && a->stride != 1))
+        return DCVC_E_ARG;
+    if (a->zs < 1 || (a->Ho - 1) * a->zs >= a->Hd || (a->Wo - 1) * a->zs >= a->Wd) return DCVC_E_ARG;
+    if (a->cin_offset < 0 || a->cin_offset + a->C > a->Cin_total) return DCVC_E_ARG;
+    const int pad = a->ks / 2;
+    if ((a->Hin + 2 * pad - a->ks) / a->stride + 1 != a->Ho || (a->Win + 2 * pad - a->ks) / a->stride + 1 != a->Wo)
+        return DCVC_E_ARG;
+    const int64_t per_split = dcvc_conv_wgrad_scratch_min(a->Cout, a->C, a->ks);
+    if (a->scratch_floats < per_split) return DCVC_E_ARG;
+    WgradK k;
+    k.x = a->x;
+    k.x_cs = a->x_cs;
+    k.C = a->C;
+    k.in_act = a->in_act;
+    k.in_slope = a->in_slope;
+    k.dpre = a->dpre;
+    k.dpre_cs = a->dpre_cs;
+    k.zs = a->zs;
+    k.Hd = a->Hd;
+    k.Wd = a->Wd;
+    k.N = a->N;
+    k.Hin = a->Hin;
+    k.Win = a->Win;
+    k.Ho = a->Ho;
+    k.Wo = a->Wo;
+    k.Cout = a->Cout;
+    k.scratch = a->scratch;
+    k.nci = (a->C + 31) / 32;
+    const int nco = (a->Cout + 31) / 32, nct = nco * k.nci;
+    const int TW = a->stride == 1 ? 32 : 16;
+    k.ntx = (a->Wo + TW - 1) / TW;
+    k.nty = (a->Ho + 3) / 4;
+    k.T = a->ks * a->ks;
+    const int groups = a->ks == 7 ? 7 : 1;
+    const int64_t ntiles = (int64_t)a->N * k.ntx * k.nty;
+    int64_t splits = 2048 / ((int64_t)nct * groups);
+    if (splits < 1) splits = 1;
+    if (splits > 256) splits = 256;
+    if (splits > ntiles) splits = ntiles;
+    if (splits > a->scratch_floats / per_split) splits = a->scratch_floats / per_split;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid((unsigned)splits, (unsigned)nct, (unsigned)groups);
+    if (a->ks == 3 && a->stride == 1) hipLaunchKernelGGL((wgrad_kernel<3, 1>), grid, dim3(256), 0, st, k);
+    else if (a->ks == 3) hipLaunchKernelGGL((wgrad_kernel<3, 2>), grid, dim3(256), 0, st, k);
+    else if (a->ks == 1 && a->stride == 1) hipLaunchKernelGGL((wgrad_kernel<1, 1>), grid, dim3(256), 0, st, k);
+    else if (a->ks == 1) hipLaunchKernelGGL((wgrad_kernel<1, 2>), grid, dim3(256), 0, st, k);
+    else hipLaunchKernelGGL((wgrad_kernel<7, 1>), grid, dim3(256), 0, st, k);
+    if (hipGetLastError() != hipSuccess) return DCVC_E_LAUNCH;
+    const int64_t nel = (int64_t)a->Cout * a->C * k.T;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(nblk(nel, 256)), dim3(256), 0, st, a->scratch, a->dw, (int)splits, nct,
+                       k.nci, k.T, a->Cout, a->C, a->Cin_total, a->cin_offset);
+    RET_LAUNCH();
+}
+
+extern "C" int dcvc_channel_dot(const float *a, int32_t a_cs, const float *b, int32_t b_cs, float *out, float *scratch,
+                                int32_t N, int32_t HW, int32_t C, int32_t over_batch, int32_t accumulate, void *stream) {
+    if (!a || !out || !scratch || N <= 0 || HW <= 0 || C <= 0) return DCVC_E_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const int Cl = C < 256 ? C : 256;
+    const int G = 256 / Cl;
+    int NB = (HW + G * 16 - 1) / (G * 16);
+    NB = NB < 1 ? 1 : (NB > 256 ? 256 : NB);
+    hipLaunchKernelGGL(channel_dot_partial, dim3(NB, N, (C + 255) / 256), dim3(256), 0, st, a, a_cs, b, b_cs, scratch, HW,
+                       C, NB);
+    hipLaunchKernelGGL(channel_dot_finish, dim3((C + 255) / 256, over_batch ? 1 : N), dim3(256), 0, st, scratch, out, N,
+                       C, NB, over_batch, accumulate);
+    RET_LAUNCH();
+}
+
+extern "C" int dcvc_mask_accumulate(const float *src, int32_t src_cs, const float *x, int32_t x_cs, float slope,
+                                    float *dst, int32_t dst_cs, int64_t npix, int32_t C, void *stream) {
+    if (!src || !dst || npix <= 0 || C <= 0) return DCVC_E_ARG;
+    hipLaunchKernelGGL(mask_accumulate_kernel, dim3(nblk(npix * C, 256)), dim3(256), 0, (hipStream_t)stream, src, src_cs,
+                       x, x_cs, slope, dst, dst_cs, npix, C);
+    RET_LAUNCH();
+}
+
+extern "C" int dcvc_add_planes(const float *a, int32_t a_cs, const float *b, int32_t b_cs, float *out, int32_t out_cs,
+                               int64_t npix, int32_t C, void *stream) {
+    if (!a || !b || !out || npix <= 0 || C <= 0) return DCVC_E_ARG;
+    hipLaunchKernelGGL(add_planes_kernel, dim3(nblk(npix * C, 256)), dim3(256), 0, (hipStream_t)stream, a, a_cs, b, b_cs,
+                       out, out_cs, npix, C);
+    RET_LAUNCH();
+}
+
+extern "C" int dcvc_warp_bwd(const float *src, int32_t src_cs, const float *flow, int32_t flow_cs, const float *dout,
+                             int32_t dout_cs, float *dsrc, int32_t dsrc_cs, float *dflow, int32_t dflow_cs, int32_t N,
+                             int32_t H, int32_t W, int32_t C, void *stream) {
+    if (!src || !flow || !dout || (!dsrc && !dflow) || N <= 0 || H <= 1 || W <= 1 || C <= 0) return DCVC_E_ARG;
+    int Cl = 1;
+    while (Cl * 2 <= C && Cl < 64) Cl *= 2;  // threads per pixel (power of two <= 64)
+    const int64_t npix = (int64_t)N * H * W;
+    dim3 block(Cl, 256 / Cl);
+    hipLaunchKernelGGL(warp_bwd_kernel, dim3(nblk(npix, 256 / Cl)), block, 0, (hipStream_t)stream, src, src_cs, flow,
+                       flow_cs, dout, dout_cs, dsrc, dsrc_cs, dflow, dflow_cs, N, H, W, C);
+    RET_LAUNCH();
+}
+
+extern "C" int dcvc_up2_bwd(const float *dout, int32_t dout_cs, float *dsrc, int32_t dsrc_cs, int32_t N, int32_t H,
+                            int32_t W, int32_t C, float scale, void *stream) {
+    if (!dout || !dsrc || N <= 0 || H <= 0 || W <= 0 || C <= 0) return DCVC_E_ARG;
+    const int64_t total = (int64_t)N * 4 * H * W * C;
+    hipLaunchKernelGGL(up2_bwd_kernel, dim3(nblk(total, 256)), dim3(256), 0, (hipStream_t)stream, dout, dout_cs, dsrc,
+                       dsrc_cs, N, H, W, C, scale);
+    RET_LAUNCH();
+}
+
+extern "C" int dcvc_down2_bwd(const float *dout, int32_t dout_cs, float *dsrc, int32_t dsrc_cs, int32_t N, int32_t H,
+                              int32_t W, int32_t C, float scale, void *stream) {
+    if (!dout || !dsrc || N <= 0 || H < 2 || W < 2 || (H & 1) || (W & 1) || C <= 0) return DCVC_E_ARG;
+    const int64_t total = (int64_t)N * H * W * C;
+    hipLaunchKernelGGL(down2_bwd_kernel, dim3(nblk(total, 256)), dim3(256), 0, (hipStream_t)stream, dout, dout_cs, dsrc,
+                       dsrc_cs, N, H, W, C, scale * 0.25f);
+    RET_LAUNCH();
+}
+
+extern "C" int dcvc_maxpool2_bwd(const float *src, int32_t src_cs, const float *dout, int32_t dout_cs, float *dsrc,
+                                 int32_t dsrc_cs, int32_t N, int32_t H, int32_t W, int32_t C, void *stream) {
+    if (!src || !dout || !dsrc || N <= 0 || H < 2 || W < 2 || (H & 1) || (W & 1) || C <= 0) return DCVC_E_ARG;
+    const int64_t total = (int64_t)N * (H / 2) * (W / 2) * C;
+    hipLaunchKernelGGL(maxpool2_bwd_kernel, dim3(nblk(total, 256)), dim3(256), 0, (hipStream_t)stream, src, src_cs, dout,
+                       dout_cs, dsrc, dsrc_cs, N, H, W, C);
+    RET_LAUNCH();
+}
+
+extern "C" int dcvc_se_bwd(const float *mean, const float *w1, const float *w2, const float *gate, const float *dgate,
+                           float *dmean, float *dw1, float *dw2, int32_t N, int32_t C, int32_t Cr, void *stream) {
+    if (!mean || !w1 || !w2 || !gate || !dgate || !dmean || C > 256 || Cr > 64 || Cr <= 0 || N <= 0) return DCVC_E_ARG;
+    hipLaunchKernelGGL(se_bwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, mean, w1, w2, gate, dgate, dmean, dw1,
+                       dw2, N, C, Cr);
+    RET_LAUNCH();
+}
+
+extern "C" int dcvc_add_channel_vec(float *dst, int32_t dst_cs, const float *vec, float scale, int32_t N, int32_t HW,
+                                    int32_t C, void *stream) {
+    if (!dst || !vec || N <= 0 || HW <= 0 || C <= 0) return DCVC_E_ARG;
+    const int64_t total = (int64_t)N * HW * C;
+    hipLaunchKernelGGL(add_channel_vec_kernel, dim3(nblk(total, 256)), dim3(256), 0, (hipStream_t)stream, dst, dst_cs,
+                       vec, scale, (int64_t)HW, C, total);
+    RET_LAUNCH();
+}
+
+extern "C" int dcvc_scale_channels_bwd(const float *dout, int32_t dout_cs, float *dsrc, int32_t dsrc_cs,
+                                       const float *q_basic, const float *q_scale, int32_t mode, int32_t N, int32_t HW,
+                                       int32_t C, void *stream) {
+    if (!dout || !dsrc || !q_basic || !q_scale) return DCVC_E_ARG;
+    const int64_t total = (int64_t)N * HW * C;
+    hipLaunchKernelGGL(scale_channels_bwd_kernel, dim3(nblk(total, 256)), dim3(256), 0, (hipStream_t)stream, dout,
+                       dout_cs, dsrc, dsrc_cs, q_basic, q_scale, mode, (int64_t)HW, C, total);
+    RET_LAUNCH();
+}
+
+extern "C" int dcvc_q_finish(const float *dq_mul, const float *s_div, const float *q_basic, const float *q_scale,
+                             float *dq_basic, float *dq_scale, int32_t N, int32_t C, void *stream) {
+    if ((!dq_mul && !s_div) || !q_basic || !q_scale || N <= 0 || C <= 0) return DCVC_E_ARG;
+    hipLaunchKernelGGL(q_finish_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, dq_mul, s_div, q_basic, q_scale,
+                       dq_basic, dq_scale, N, C);
+    RET_LAUNCH();
+}
+
+extern "C" int dcvc_dual_prior_bwd(const dcvc_dual_prior_bwd_args *a, void *stream) {
+    if (!a || (a->C & 1) || a->N <= 0 || (a->step != 0 && a->step != 1)) return DCVC_E_ARG;
+    if (a->step == 1 && !a->dspatial) return DCVC_E_ARG;
+    if (a->step == 0 && (!a->y || !a->fusion || !a->y_hat || !a->dfusion || !a->q_basic || !a->q_scale)) return DCVC_E_ARG;
+    const int64_t total = (int64_t)a->N * a->H * a->W * a->C;
+    hipLaunchKernelGGL(dual_prior_bwd_kernel, dim3(nblk(total, 256)), dim3(256), 0, (hipStream_t)stream, *a, total);
+    RET_LAUNCH();
+}
+
+extern "C" int dcvc_scale_bits_bwd(const float *y, const float *scales_hat, const float *g, float *dy, float *dscales,
+                                   int32_t N, int64_t per_sample, void *stream) {
+    if (!y || !scales_hat || !g || !dy || !dscales || N <= 0 || per_sample <= 0) return DCVC_E_ARG;
+    const int64_t total = (int64_t)N * per_sample;
+    hipLaunchKernelGGL(scale_bits_bwd_kernel, dim3(nblk(total, 256)), dim3(256), 0, (hipStream_t)stream, y, scales_hat, g,
+                       dy, dscales, per_sample, total);
+    RET_LAUNCH();
+}
+
+extern "C" int dcvc_factorized_bits_bwd(const float *z, int32_t z_cs, const float *params, const float *g, float *dz,
+                                        int32_t dz_cs, float *dparams, int32_t N, int32_t HW, int32_t C, void *stream) {
+    if (!z || !params || !g || (!dz && !dparams) || N <= 0 || HW <= 0 || C <= 0) return DCVC_E_ARG;
+    hipLaunchKernelGGL(factorized_bits_bwd_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, z, z_cs, params, g, dz,
+                       dz_cs, dparams, N, (int64_t)HW, C);
+    RET_LAUNCH();
+}
+
+extern "C" int dcvc_sq_err_bwd(const float *a, int32_t a_cs, const float *b, int32_t b_cs, const float *g, float *da,
+                               int32_t da_cs, int32_t N, int32_t HW, int32_t C, void *stream) {
+    if (!a || !b || !g || !da || N <= 0 || HW <= 0 || C <= 0) return DCVC_E_ARG;
+    const int64_t total = (int64_t)N * HW * C;
+    hipLaunchKernelGGL(sq_err_bwd_kernel, dim3(nblk(total, 256)), dim3(256), 0, (hipStream_t)stream, a, a_cs, b, b_cs, g,
+                       da, da_cs, (int64_t)HW, C, total);
+    RET_LAUNCH();
+}

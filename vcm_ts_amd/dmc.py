@@ -255,7 +255,7 @@ class CodecBase(nn.Module):
 
     # -- dual prior (both directions) -----------------------------------------------------
     def _dual_prior_encode(self, tag, y: View, fusion: View, prior_name, out: View, q_basic, q_scale, want_stats,
-                           want_symbols):
+                           want_symbols, want_res=False, qkey=None):
         """forward_dual_prior (common_model.py:104-177): returns dict with y_q / scales_hat
         (dense NHWC planes for the bit estimate) and the two (sym, idx) int32 pairs."""
         e, net = self.engine(), self._net
@@ -267,6 +267,8 @@ class CodecBase(nn.Module):
         if want_stats:
             r["y_q"] = e.fbuf(f"{self._tag}/{tag}.dp_yq", n)
             r["scales_hat"] = e.fbuf(f"{self._tag}/{tag}.dp_sh", n)
+        if want_res:
+            r["y_res"] = e.fbuf(f"{self._tag}/{tag}.dp_yres", n)
         sym = [None, None]
         idx = [None, None]
         if want_symbols:
@@ -274,7 +276,7 @@ class CodecBase(nn.Module):
                 sym[k] = e.ibuf(f"{self._tag}/{tag}.sym{k}", n // 2)
                 idx[k] = e.ibuf(f"{self._tag}/{tag}.idx{k}", n // 2)
         common = dict(y=y, fusion=fusion, params=params, y_hat=y_hat, y_q=r.get("y_q"), scales_hat=r.get("scales_hat"),
-                      distribution=self._distribution)
+                      y_res=r.get("y_res"), distribution=self._distribution, qkey=qkey)
         e.dual_prior("enc", 0, sym=sym[0], idx=idx[0], **common)
         spatial = net.three_convs(prior_name, params)
         e.dual_prior("enc", 1, spatial=spatial, sym=sym[1], idx=idx[1], out=out, q_basic=q_basic, q_scale=q_scale,
@@ -301,6 +303,62 @@ class CodecBase(nn.Module):
         sym = self._decode_scale(idx)
         e.dual_prior("dec_apply", 1, spatial=spatial, sym=sym, out=out, q_basic=q_basic, q_scale=q_scale, **common)
         return out
+
+
+def lib_check(code, what):
+    from . import lib
+
+    lib.check(code, what)
+
+
+class _FrameFn(torch.autograd.Function):
+    """One P picture as a single autograd node: forward records a grad.Tape on the HIP engine,
+    backward replays it with the kernels of include/dcvc_hip_grad.h.  Inputs after the q-scales
+    are all parameters of the model, so optimisers, DDP hooks and requires_grad switches
+    (DCVC_HEM.activate_modules_*) work as they do on the reference's nn.Modules."""
+
+    @staticmethod
+    def forward(ctx, model, x, dpb, qm, qy, *params):
+        from .grad import Tape
+
+        tape = Tape(model.engine())
+        o, sums = model._train_frame(tape, x.detach(), {k: (None if v is None else v.detach()) for k, v in dpb.items()},
+                                     qm.detach(), qy.detach())
+        ctx.tape, ctx.model, ctx.params = tape, model, params
+        ctx.q_shapes = (qm.shape, qy.shape)
+        d = model._dpb_out(o)
+        outs = (sums["bits_mv_y"], sums["bits_mv_z"], sums["bits_y"], sums["bits_z"], sums["sq"], sums["me_sq"],
+                d["ref_frame"], d["ref_feature"], d["ref_y"], d["ref_mv_y"])
+        ctx.mark_non_differentiable(*outs[6:])
+        return outs
+
+    @staticmethod
+    def backward(ctx, g_mv_y, g_mv_z, g_y, g_z, g_sq, g_me, *_):
+        tape = ctx.tape
+        if tape is None:
+            raise RuntimeError("this frame's tape was already consumed (retain_graph is not supported)")
+        for name, g in (("bits_mv_y", g_mv_y), ("bits_mv_z", g_mv_z), ("bits_y", g_y), ("bits_z", g_z), ("sq", g_sq),
+                        ("me_sq", g_me)):
+            if g is not None:
+                tape.up[name] = g.detach().to(torch.float32).contiguous()
+        tape.backward()
+        grads = []
+        for p, need in zip(ctx.params, ctx.needs_input_grad[5:]):
+            grads.append(tape.pgrads.get(id(p)) if need else None)
+
+        def qgrad(key, shape, need):
+            if not need:
+                return None
+            g = tape.q[key]["dq_scale"]
+            n = 1
+            for s_ in shape:
+                n *= s_
+            return (g.sum() if n == 1 else g).reshape(shape)
+
+        gqm = qgrad("mv", ctx.q_shapes[0], ctx.needs_input_grad[3])
+        gqy = qgrad("y", ctx.q_shapes[1], ctx.needs_input_grad[4])
+        ctx.tape = None
+        return (None, None, None, gqm, gqy, *grads)
 
 
 class DMC(CodecBase):
@@ -334,7 +392,8 @@ class DMC(CodecBase):
             self._dual_prior_decode("mv", fusion, "mv_y_spatial_prior", out, qb, q_mv)
             return out, None
         r = self._dual_prior_encode("mv", mv_y, fusion, "mv_y_spatial_prior", out, qb, q_mv,
-                                    want_stats=(mode == "estimate"), want_symbols=(mode == "compress"))
+                                    want_stats=(mode != "compress"), want_symbols=(mode == "compress"),
+                                    want_res=(mode == "train"), qkey="mv")
         return out, r
 
     def _y_prior(self, net: Net, dpb_v, c3: View, z_hat: View):
@@ -349,7 +408,7 @@ class DMC(CodecBase):
     def _views_of_dpb(self, dpb):
         return {k: self._dpb_in(k, dpb.get(k)) for k in ("ref_frame", "ref_feature", "ref_y", "ref_mv_y")}
 
-    def _run(self, x, dpb, mv_y_q_scale, y_q_scale, mode):
+    def _run(self, x, dpb, mv_y_q_scale, y_q_scale, mode, tape=None):
         """mode 'estimate' (forward_one_frame, unclamped recon as video_model.py:535) or
         'compress' (recon clamped to [0, 1] exactly as the decoder will, :413, so that the
         encoder's own DPB is bit-identical to the decoder's and no decode pass is needed)."""
@@ -360,13 +419,20 @@ class DMC(CodecBase):
         q_mv = self._qvec(mv_y_q_scale, N, "mv_y_q_scale")
         q_y = self._qvec(y_q_scale, N, "y_q_scale")
         dv = self._views_of_dpb(dpb)
-        k = self._out_set(*dv.values())
+        k = self._out_set(*dv.values()) if tape is None else 0
         # current frame lives in channels 0-2 of SpyNet's finest 8-channel input buffer
         spy0 = e.buf("dmc/spy.in0", N, H, W, 8)
         x3 = e.from_nchw(x, spy0.slice(0, 3))
+        if tape is not None:  # pictures and (detached) DPB entries carry no gradient
+            tape.mark_const(x3)
+            for v in dv.values():
+                tape.mark_const(v)
+                if v is not None:
+                    tape.keep.append(v.base)
         est_mv = net.spynet(x3, dv["ref_frame"])
         mv_y_raw = net.encoder_stack("mv_encoder", est_mv)
-        mv_y = e.scale_channels(mv_y_raw, net.buf("mv_y", like=mv_y_raw, C=64), self.P("mv_y_q_basic").reshape(-1), q_mv)
+        mv_y = e.scale_channels(mv_y_raw, net.buf("mv_y", like=mv_y_raw, C=64), self.P("mv_y_q_basic").reshape(-1), q_mv,
+                                qkey="mv")
         mv_z = net.hyper_enc5("mv_hyper_prior_encoder", mv_y)
         mv_z_hat = net.buf("mv_z_hat", like=mv_z, C=64)
         sym_mv_z = e.ibuf("dmc/sym_mv_z", N * 64 * mv_z.HW) if mode == "compress" else None
@@ -376,9 +442,9 @@ class DMC(CodecBase):
         enc_cat2 = net.buf("enc_cat2", N=N, H=H // 2, W=W // 2, C=128)
         enc_cat3 = net.buf("enc_cat3", N=N, H=H // 4, W=W // 4, C=128)
         c1, c2, c3, warp_frame = net.motion_compensation(dv["ref_frame"], dv["ref_feature"], mv_hat, enc_cat2, enc_cat3,
-                                                         want_warp_frame=(mode == "estimate"))
+                                                         want_warp_frame=(mode != "compress"))
         y_raw = net.contextual_encoder(x3, c1, enc_cat2, enc_cat3)
-        y = e.scale_channels(y_raw, net.buf("y", like=y_raw, C=96), self.P("y_q_basic").reshape(-1), q_y)
+        y = e.scale_channels(y_raw, net.buf("y", like=y_raw, C=96), self.P("y_q_basic").reshape(-1), q_y, qkey="y")
         n_ = "contextual_hyper_prior_encoder"
         t = net.conv(f"{n_}.0", y, out_slope=0.01)
         t = net.conv(f"{n_}.2", t, stride=2, out_slope=0.01)
@@ -389,24 +455,102 @@ class DMC(CodecBase):
         fusion = self._y_prior(net, dv, c3, z_hat)
         y_hat = net.buf(f"dpb{k}.ref_y", like=y, C=96)
         r_y = self._dual_prior_encode("y", y, fusion, "y_spatial_prior", y_hat, self.P("y_q_basic").reshape(-1), q_y,
-                                      want_stats=(mode == "estimate"), want_symbols=(mode == "compress"))
+                                      want_stats=(mode != "compress"), want_symbols=(mode == "compress"),
+                                      want_res=(mode == "train"), qkey="y")
         dec_feature = net.contextual_decoder(y_hat, c2, c3)
         feature = net.buf(f"dpb{k}.ref_feature", N=N, H=H, W=W, C=64)
         recon = net.buf(f"dpb{k}.ref_frame", N=N, H=H, W=W, C=3)
         net.recon_generation(dec_feature, c1, feature, recon, clamp=(mode == "compress"))
         return dict(N=N, H=H, W=W, x3=x3, recon=recon, feature=feature, y_hat=y_hat, mv_y_hat=mv_y_hat,
                     warp_frame=warp_frame, r_mv=r_mv, r_y=r_y, mv_z_hat=mv_z_hat, z_hat=z_hat, sym_mv_z=sym_mv_z,
-                    sym_z=sym_z, est_mv=est_mv, mv_hat=mv_hat, c1=c1, c2=c2, c3=c3, y=y, mv_y=mv_y)
+                    sym_z=sym_z, est_mv=est_mv, mv_hat=mv_hat, c1=c1, c2=c2, c3=c3, y=y, mv_y=mv_y, z=z, mv_z=mv_z,
+                    q_mv=q_mv, q_y=q_y, dv=dv)
 
     @staticmethod
     def _dpb_out(o):
         return {"ref_frame": o["recon"].nchw(), "ref_feature": o["feature"].nchw(), "ref_y": o["y_hat"].nchw(),
                 "ref_mv_y": o["mv_y_hat"].nchw()}
 
+    # ------------------------------------------------------------------ training-mode forward
+    _noise_override = None  # tests: {"y", "mv_y", "z", "mv_z"} -> NCHW tensors replacing add_noise's draws
+
+    def _noise(self, key, N, H, W, C_):
+        """uniform(-0.5, 0.5) like CompressionModel.add_noise (common_model.py:46-49), dense NHWC."""
+        if self._noise_override is not None:
+            t = self._noise_override[key].to(device=self.device, dtype=torch.float32)
+            assert tuple(t.shape) == (N, C_, H, W), (key, t.shape)
+            return t.permute(0, 2, 3, 1).contiguous()
+        return torch.empty((N, H, W, C_), dtype=torch.float32, device=self.device).uniform_(-0.5, 0.5)
+
+    def _train_frame(self, tape, x, dpb, mv_y_q_scale, y_q_scale):
+        """Recorded forward: everything forward_one_frame computes in training mode
+        (video_model.py:470-596 with self.training: straight-through rounding, noisy latents for
+        the bit estimate).  Returns per-sample sums (bits_*, squared errors) and the DPB views."""
+        e = self.engine()
+        e.tape = tape
+        try:
+            N = x.shape[0]
+            tape.qstate("mv", self.P("mv_y_q_basic"), self._qvec(mv_y_q_scale, N, "mv_y_q_scale"), N, 64)
+            tape.qstate("y", self.P("y_q_basic"), self._qvec(y_q_scale, N, "y_q_scale"), N, 96)
+            o = self._run(x, dpb, tape.q["mv"]["q_scale"], tape.q["y"]["q_scale"], "train", tape=tape)
+            L = e.L
+            sums = {}
+            sums["sq"] = e.sq_err(o["recon"], o["x3"])
+            tape.ops.append(("sq_err", "sq", o["recon"], o["x3"]))
+            sums["me_sq"] = e.sq_err(o["warp_frame"], o["x3"])
+            tape.ops.append(("sq_err", "me_sq", o["warp_frame"], o["x3"]))
+            for name, r, lat, nkey in (("bits_y", o["r_y"], o["y"], "y"), ("bits_mv_y", o["r_mv"], o["mv_y"], "mv_y")):
+                per = lat.HW * lat.C
+                noise = self._noise(nkey, N, lat.H, lat.W, lat.C)
+                y_bit = torch.empty_like(noise).view(-1)
+                lib_check(L.dcvc_add_planes(r["y_res"].data_ptr(), lat.C, noise.data_ptr(), lat.C, y_bit.data_ptr(), lat.C,
+                                            N * lat.HW, lat.C, e.stream()), "add_planes")
+                sums[name] = e.scale_bits(y_bit, r["scales_hat"], N, per)
+                tape.ops.append(("scale_bits", name, y_bit, r["scales_hat"], r["y_res"], N, per))
+            for name, z, est, nkey in (("bits_z", o["z"], "bit_estimator_z", "z"),
+                                       ("bits_mv_z", o["mv_z"], "bit_estimator_z_mv", "mv_z")):
+                noise = self._noise(nkey, N, z.H, z.W, z.C)
+                z_bit = View(torch.empty_like(noise), z.C)
+                lib_check(L.dcvc_add_planes(z.ptr, z.cs, noise.data_ptr(), z.C, z_bit.ptr, z_bit.cs, N * z.HW, z.C,
+                                            e.stream()), "add_planes")
+                blk = self._zblock(est)
+                sums[name] = e.factorized_bits(z_bit, blk)
+                plist = [self.P(f"{est}.f{i}.{k}") for i in (1, 2, 3) for k in ("h", "b", "a")]
+                plist += [self.P(f"{est}.f4.h"), self.P(f"{est}.f4.b")]
+                tape.ops.append(("factorized_bits", name, z_bit, z, blk, plist))
+            return o, sums
+        finally:
+            e.tape = None
+
+    def _forward_train(self, x, dpb, mv_y_q_scale, y_q_scale):
+        if any(dpb.get(k) is not None and dpb[k].requires_grad for k in ("ref_frame", "ref_feature", "ref_y", "ref_mv_y")):
+            raise NotImplementedError("gradients through the DPB (the reference's cascade training modes) are not built "
+                                      "yet: detach the DPB entries (single / single_multi modes do)")
+        qm = self.P("mv_y_q_scale") if mv_y_q_scale is None else mv_y_q_scale
+        qy = self.P("y_q_scale") if y_q_scale is None else y_q_scale
+        qm = qm if torch.is_tensor(qm) else torch.tensor(float(qm), device=self.device)
+        qy = qy if torch.is_tensor(qy) else torch.tensor(float(qy), device=self.device)
+        params = list(self._pmap.values())
+        outs = _FrameFn.apply(self, x, dpb, qm, qy, *params)
+        bits_mv_y, bits_mv_z, bits_y, bits_z, sq, me_sq, recon, feature, y_hat, mv_y_hat = outs
+        pix = x.shape[2] * x.shape[3]
+        bpp_y, bpp_z, bpp_mv_y, bpp_mv_z = bits_y / pix, bits_z / pix, bits_mv_y / pix, bits_mv_z / pix
+        bpp = bpp_y + bpp_z + bpp_mv_y + bpp_mv_z
+        res = {"bpp_mv_y": bpp_mv_y, "bpp_mv_z": bpp_mv_z, "bpp_y": bpp_y, "bpp_z": bpp_z, "bpp": bpp,
+               "me_mse": me_sq / pix, "mse": sq / pix,
+               "dpb": {"ref_frame": recon, "ref_feature": feature, "ref_y": y_hat, "ref_mv_y": mv_y_hat}}
+        for key, v in (("bit", bpp), ("bit_y", bpp_y), ("bit_z", bpp_z), ("bit_mv_y", bpp_mv_y), ("bit_mv_z", bpp_mv_z)):
+            res[key] = torch.sum(v) * pix
+        return res
+
     # ------------------------------------------------------------------ public API
-    @torch.no_grad()
     def forward_one_frame(self, x, dpb, mv_y_q_scale=None, y_q_scale=None):
-        self._eval_only()
+        if self.training:
+            return self._forward_train(x, dpb, mv_y_q_scale, y_q_scale)
+        with torch.no_grad():
+            return self._forward_eval(x, dpb, mv_y_q_scale, y_q_scale)
+
+    def _forward_eval(self, x, dpb, mv_y_q_scale=None, y_q_scale=None):
         e = self.engine()
         o = self._run(x, dpb, mv_y_q_scale, y_q_scale, "estimate")
         N, pix = o["N"], o["H"] * o["W"]

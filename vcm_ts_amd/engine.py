@@ -71,7 +71,8 @@ class View:
 
 
 class PackedConv:
-    __slots__ = ("w", "b", "ks", "Cout", "Cout_pad", "seg_C", "ps", "version", "precision")
+    __slots__ = ("w", "b", "ks", "Cout", "Cout_pad", "seg_C", "ps", "version", "precision", "weight", "bias",
+                 "cin_slice", "key")
 
 
 class Engine:
@@ -90,35 +91,56 @@ class Engine:
         self.calls = 0
         self.profile = None  # set to {} to time every conv launch with HIP events (bench.py)
         self.profile_detail = None
+        self.tape = None     # grad.Tape while a training-mode forward is being recorded
 
     # ------------------------------------------------------------------ memory
     def stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
+    def _store(self, scratch=False):
+        """Inference recycles one named workspace; a recorded (training) forward owns fresh buffers
+        that live as long as its tape, because backward reads every intermediate."""
+        return self.bufs if (self.tape is None or scratch) else self.tape.arena
+
     def buf(self, name, N, H, W, C_, cs=None, zero=False) -> View:
         cs = cs or _r4(C_)
         key = (name, N, H, W, cs)
-        t = self.bufs.get(key)
+        store = self._store()
+        t = store.get(key)
         if t is None:
             t = (torch.zeros if zero else torch.empty)((N, H, W, cs), dtype=torch.float32, device=self.device)
-            self.bufs[key] = t
+            store[key] = t
         return View(t, C_)
 
     def ibuf(self, name, n) -> torch.Tensor:
         key = (name, n, "i32")
-        t = self.bufs.get(key)
+        store = self._store()
+        t = store.get(key)
         if t is None:
             t = torch.empty(n, dtype=torch.int32, device=self.device)
-            self.bufs[key] = t
+            store[key] = t
         return t
 
-    def fbuf(self, name, n) -> torch.Tensor:
+    def fbuf(self, name, n, scratch=False) -> torch.Tensor:
         key = (name, n, "f32")
-        t = self.bufs.get(key)
+        store = self._store(scratch)
+        t = store.get(key)
         if t is None:
             t = torch.empty(n, dtype=torch.float32, device=self.device)
-            self.bufs[key] = t
+            store[key] = t
         return t
+
+    def _rec(self, *op):
+        if self.tape is not None:
+            self.tape.ops.append(op)
+
+    def _rec_unary(self, name, src, out, *rest):
+        """Resamplings of a gradient-free input (picture pyramids) stay gradient-free."""
+        if self.tape is not None:
+            if self.tape.is_const(src):
+                self.tape.mark_const(out)
+            else:
+                self.tape.ops.append((name, src, out) + rest)
 
     def release(self):
         self.bufs.clear()
@@ -154,7 +176,47 @@ class Engine:
         return out
 
     # ------------------------------------------------------------------ convolution
+    def pack_dev(self, key, weight: torch.Tensor, bias, seg_C, ps, cin_slice=None, transposed=False) -> PackedConv:
+        """Device-side packing (dcvc_conv_pack_weights_dev): used while training, where the weights
+        change every optimiser step, and for the transposed filters of the data gradient."""
+        ver = (weight._version, None if bias is None else bias._version, weight.data_ptr())
+        key = (key, self.precision, "dev", bool(transposed))
+        pk = self.packs.get(key)
+        if pk is not None and pk.version == ver:
+            return pk
+        Cout, CinT, ks, _ = weight.shape
+        off = 0 if cin_slice is None else cin_slice[0]
+        if transposed:
+            assert len(seg_C) == 1 and not ps
+            pk_cout, pk_segs = seg_C[0], (Cout,)
+        else:
+            pk_cout, pk_segs = Cout, tuple(seg_C)
+        if pk is None:
+            segs = (C.c_int32 * len(pk_segs))(*pk_segs)
+            cpad = C.c_int32()
+            n = self.L.dcvc_conv_pack_size(pk_cout, ks, len(pk_segs), segs, C.byref(cpad))
+            if n < 0:
+                raise lib.KernelError(f"conv_pack_size({key})")
+            pk = PackedConv()
+            pk.w = torch.empty(n, dtype=torch.float32, device=self.device)
+            pk.b = torch.empty(cpad.value, dtype=torch.float32, device=self.device)
+            pk.ks, pk.Cout, pk.Cout_pad, pk.seg_C, pk.ps = ks, pk_cout, cpad.value, pk_segs, bool(ps)
+            pk.precision = lib.PRECISIONS[self.precision]
+            pk.key = key
+            self.packs[key] = pk
+        assert weight.is_contiguous() and weight.dtype == torch.float32 and weight.device == self.device
+        segs = (C.c_int32 * len(seg_C))(*seg_C)
+        lib.check(self.L.dcvc_conv_pack_weights_dev(weight.data_ptr(), None if (bias is None or transposed) else bias.data_ptr(),
+                                                    Cout, CinT, ks, len(seg_C), segs, off, int(ps), pk.precision,
+                                                    int(transposed), pk.w.data_ptr(), pk.b.data_ptr(), self.stream()),
+                  f"conv_pack_weights_dev({key})")
+        pk.version = ver
+        pk.weight, pk.bias, pk.cin_slice = weight, bias, cin_slice
+        return pk
+
     def pack(self, key, weight: torch.Tensor, bias, seg_C, ps, cin_slice=None) -> PackedConv:
+        if self.tape is not None:
+            return self.pack_dev(key, weight, bias, seg_C, ps, cin_slice)
         ver = (weight._version, None if bias is None else bias._version, weight.data_ptr())
         key = (key, self.precision)
         pk = self.packs.get(key)
@@ -183,6 +245,7 @@ class Engine:
         pk.b = torch.from_numpy(bp).to(self.device)
         pk.ks, pk.Cout, pk.Cout_pad, pk.seg_C, pk.ps, pk.version = ks, Cout, cpad.value, tuple(seg_C), bool(ps), ver
         pk.precision = lib.PRECISIONS[self.precision]
+        pk.weight, pk.bias, pk.cin_slice, pk.key = weight, bias, cin_slice, key
         self.packs[key] = pk
         return pk
 
@@ -232,6 +295,7 @@ class Engine:
                 self.profile_detail.append((ev0, ev1, flops, f"k{pk.ks}s{stride} {pk.seg_C}->{pk.Cout}{'ps' if pk.ps else ''} "
                                                              f"{s0.H}x{s0.W}"))
         self.calls += 1
+        self._rec("conv", pk, tuple(srcs), out, stride, in_slope, out_slope, res, gate, res2)
         return out
 
     def collect_profile(self):
@@ -245,36 +309,41 @@ class Engine:
         lib.check(self.L.dcvc_warp(src.ptr, src.cs, flow.ptr, flow.cs, out.ptr, out.cs, src.N, src.H, src.W, src.C,
                                    self.stream()), "warp")
         self.calls += 1
+        self._rec("warp", src, flow, out)
         return out
 
     def up2(self, src: View, out: View, scale=1.0, out2: View = None):
         lib.check(self.L.dcvc_up2(src.ptr, src.cs, out.ptr, out.cs, out2.ptr if out2 else None,
                                   out2.cs if out2 else 0, src.N, src.H, src.W, src.C, scale, self.stream()), "up2")
         self.calls += 1
+        self._rec("up2", src, out, scale, out2)
         return out
 
     def down2(self, src: View, out: View, scale=1.0, avgpool_order=False):
         lib.check(self.L.dcvc_down2(src.ptr, src.cs, out.ptr, out.cs, src.N, src.H, src.W, src.C, scale,
                                     int(avgpool_order), self.stream()), "down2")
         self.calls += 1
+        self._rec_unary("down2", src, out, scale)
         return out
 
     def maxpool2(self, src: View, out: View):
         lib.check(self.L.dcvc_maxpool2(src.ptr, src.cs, out.ptr, out.cs, src.N, src.H, src.W, src.C, self.stream()),
                   "maxpool2")
         self.calls += 1
+        self._rec_unary("maxpool2", src, out)
         return out
 
     def copy(self, src: View, out: View):
         lib.check(self.L.dcvc_copy_channels(src.ptr, src.cs, out.ptr, out.cs, src.N * src.H * src.W, src.C,
                                             self.stream()), "copy_channels")
         self.calls += 1
+        self._rec_unary("copy", src, out)
         return out
 
     # ------------------------------------------------------------------ SE
     def se_gate(self, name, t: View, w1: torch.Tensor, w2: torch.Tensor) -> torch.Tensor:
         N, C_ = t.N, t.C
-        scratch = self.fbuf("se_scratch", N * 2048 * 256)
+        scratch = self.fbuf("se_scratch", N * 2048 * 256, scratch=True)
         mean = self.fbuf(name + ".mean", N * C_)
         gate = self.fbuf(name + ".gate", N * C_)
         lib.check(self.L.dcvc_channel_mean(t.ptr, t.cs, mean.data_ptr(), scratch.data_ptr(), N, t.HW, C_,
@@ -282,13 +351,15 @@ class Engine:
         lib.check(self.L.dcvc_se_gate(mean.data_ptr(), w1.data_ptr(), w2.data_ptr(), gate.data_ptr(), N, C_,
                                       w1.shape[0], self.stream()), "se_gate")
         self.calls += 2
+        self._rec("se_gate", t, w1, w2, mean, gate)
         return gate
 
     # ------------------------------------------------------------------ entropy-model elementwise
-    def scale_channels(self, src: View, out: View, q_basic, q_scale, multiply=False):
+    def scale_channels(self, src: View, out: View, q_basic, q_scale, multiply=False, qkey=None):
         lib.check(self.L.dcvc_scale_channels(src.ptr, src.cs, out.ptr, out.cs, q_basic.data_ptr(), q_scale.data_ptr(),
                                              int(multiply), src.N, src.HW, src.C, self.stream()), "scale_channels")
         self.calls += 1
+        self._rec("scale_channels", src, out, q_basic, q_scale, multiply, qkey)
         return out
 
     def round_symbols(self, z: View, z_hat: View, sym: torch.Tensor = None):
@@ -296,6 +367,8 @@ class Engine:
                                             sym.data_ptr() if sym is not None else None, z.N, z.H, z.W, z.C,
                                             self.stream()), "round_symbols")
         self.calls += 1
+        if z_hat is not None:
+            self._rec("round", z, z_hat)
 
     def symbols_to_nhwc(self, sym: torch.Tensor, out: View):
         lib.check(self.L.dcvc_symbols_to_nhwc(sym.data_ptr(), out.ptr, out.cs, out.N, out.H, out.W, out.C,
@@ -305,7 +378,7 @@ class Engine:
 
     def dual_prior(self, mode, step, *, y: View = None, fusion: View, spatial: View = None, params: View,
                    y_hat: torch.Tensor, y_q=None, y_res=None, scales_hat=None, sym=None, idx=None, out: View = None,
-                   q_basic=None, q_scale=None, distribution="laplace"):
+                   q_basic=None, q_scale=None, distribution="laplace", qkey=None):
         a = lib.DualPriorArgs()
         Cc = fusion.C // 3
         if y is not None:
@@ -329,9 +402,12 @@ class Engine:
               "dec_apply": self.L.dcvc_dual_prior_dec_apply}[mode]
         lib.check(fn(C.byref(a), self.stream()), "dual_prior_" + mode)
         self.calls += 1
+        if mode == "enc":
+            self._rec("dual_prior", step, y, fusion, spatial, params, y_hat, y_res, scales_hat, out, q_basic, q_scale,
+                      qkey)
 
     def _scratch(self, N):
-        return self.fbuf("reduce_scratch", N * 1024)
+        return self.fbuf("reduce_scratch", N * 1024, scratch=True)
 
     def scale_bits(self, y_q, scales_hat, N, per_sample, gaussian=False) -> torch.Tensor:
         out = torch.empty(N, dtype=torch.float32, device=self.device)

@@ -84,6 +84,39 @@ class DualPriorArgs(C.Structure):
     ]
 
 
+class ConvBwdArgs(C.Structure):
+    _fields_ = [
+        ("dout", C.c_void_p), ("dout_cs", C.c_int32), ("out", C.c_void_p), ("out_cs", C.c_int32),
+        ("res", C.c_void_p), ("res_cs", C.c_int32), ("gate", C.c_void_p), ("res2", C.c_void_p), ("res2_cs", C.c_int32),
+        ("dres", C.c_void_p), ("dres_cs", C.c_int32), ("dres2", C.c_void_p), ("dres2_cs", C.c_int32),
+        ("dpre", C.c_void_p), ("dpre_cs", C.c_int32), ("zs", C.c_int32), ("Hd", C.c_int32), ("Wd", C.c_int32),
+        ("N", C.c_int32), ("Ho", C.c_int32), ("Wo", C.c_int32), ("Cout", C.c_int32), ("pixel_shuffle", C.c_int32),
+        ("act", C.c_int32), ("slope", C.c_float),
+    ]
+
+
+class WgradArgs(C.Structure):
+    _fields_ = [
+        ("x", C.c_void_p), ("x_cs", C.c_int32), ("C", C.c_int32), ("in_act", C.c_int32), ("in_slope", C.c_float),
+        ("dpre", C.c_void_p), ("dpre_cs", C.c_int32), ("zs", C.c_int32), ("Hd", C.c_int32), ("Wd", C.c_int32),
+        ("N", C.c_int32), ("Hin", C.c_int32), ("Win", C.c_int32), ("Ho", C.c_int32), ("Wo", C.c_int32),
+        ("Cout", C.c_int32), ("ks", C.c_int32), ("stride", C.c_int32), ("dw", C.c_void_p), ("Cin_total", C.c_int32),
+        ("cin_offset", C.c_int32), ("scratch", C.c_void_p), ("scratch_floats", C.c_int64),
+    ]
+
+
+class DualPriorBwdArgs(C.Structure):
+    _fields_ = [
+        ("y", C.c_void_p), ("y_cs", C.c_int32), ("fusion", C.c_void_p), ("fusion_cs", C.c_int32),
+        ("y_hat", C.c_void_p), ("dout", C.c_void_p), ("dout_cs", C.c_int32), ("dy_res", C.c_void_p),
+        ("dscales_hat", C.c_void_p), ("dparams", C.c_void_p), ("dparams_cs", C.c_int32),
+        ("dspatial", C.c_void_p), ("dspatial_cs", C.c_int32), ("dy", C.c_void_p), ("dy_cs", C.c_int32),
+        ("dfusion", C.c_void_p), ("dfusion_cs", C.c_int32), ("dq_plane", C.c_void_p),
+        ("q_basic", C.c_void_p), ("q_scale", C.c_void_p), ("N", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
+        ("C", C.c_int32), ("step", C.c_int32),
+    ]
+
+
 PRECISIONS = {"fp32": 0, "fp16x3": 1}
 
 _hip = None
@@ -110,9 +143,28 @@ _SIGS = {
     "dcvc_scale_bits": [vp, vp, vp, vp, i32, i32, i64, vp],
     "dcvc_factorized_bits": [vp, i32, vp, vp, vp, i32, i32, i32, vp],
     "dcvc_sq_err": [vp, i32, vp, i32, vp, vp, i32, i32, i32, vp],
+    # include/dcvc_hip_grad.h
+    "dcvc_conv_pack_weights_dev": [vp, vp, i32, i32, i32, i32, vp, i32, i32, i32, i32, vp, vp, vp],
+    "dcvc_conv_bwd_prologue": [C.POINTER(ConvBwdArgs), vp],
+    "dcvc_conv_wgrad": [C.POINTER(WgradArgs), vp],
+    "dcvc_channel_dot": [vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, i32, vp],
+    "dcvc_mask_accumulate": [vp, i32, vp, i32, f32, vp, i32, i64, i32, vp],
+    "dcvc_add_planes": [vp, i32, vp, i32, vp, i32, i64, i32, vp],
+    "dcvc_warp_bwd": [vp, i32, vp, i32, vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, vp],
+    "dcvc_up2_bwd": [vp, i32, vp, i32, i32, i32, i32, i32, f32, vp],
+    "dcvc_down2_bwd": [vp, i32, vp, i32, i32, i32, i32, i32, f32, vp],
+    "dcvc_maxpool2_bwd": [vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, vp],
+    "dcvc_se_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp],
+    "dcvc_add_channel_vec": [vp, i32, vp, f32, i32, i32, i32, vp],
+    "dcvc_scale_channels_bwd": [vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, vp],
+    "dcvc_q_finish": [vp, vp, vp, vp, vp, vp, i32, i32, vp],
+    "dcvc_dual_prior_bwd": [C.POINTER(DualPriorBwdArgs), vp],
+    "dcvc_scale_bits_bwd": [vp, vp, vp, vp, vp, i32, i64, vp],
+    "dcvc_factorized_bits_bwd": [vp, i32, vp, vp, vp, i32, vp, i32, i32, i32, vp],
+    "dcvc_sq_err_bwd": [vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, vp],
 }
 
-HIP_SYMBOLS = sorted(list(_SIGS) + ["dcvc_conv_pack_size", "dcvc_hip_version"])
+HIP_SYMBOLS = sorted(list(_SIGS) + ["dcvc_conv_pack_size", "dcvc_hip_version", "dcvc_conv_wgrad_scratch_min"])
 RANS_SYMBOLS = [
     "dcvc_rans_encoder_create", "dcvc_rans_encoder_destroy", "dcvc_rans_encoder_reset",
     "dcvc_rans_encoder_encode_with_indexes", "dcvc_rans_encoder_flush_bound", "dcvc_rans_encoder_flush",
@@ -132,6 +184,8 @@ def hip():
         L.dcvc_conv_pack_size.argtypes = [i32, i32, i32, vp, C.POINTER(i32)]
         L.dcvc_conv_pack_size.restype = i64
         L.dcvc_hip_version.restype = C.c_char_p
+        L.dcvc_conv_wgrad_scratch_min.argtypes = [i32, i32, i32]
+        L.dcvc_conv_wgrad_scratch_min.restype = i64
         _hip = L
     return _hip
 
