@@ -1,0 +1,151 @@
+"""Gradient parity of the HIP training path (include/dcvc_hip_grad.h, vcm_ts_amd/grad.py) on a
+real MI355X: per operator against torch's CPU autograd of the same operator, and for whole P
+pictures against (a) the oracle's autograd and (b) the reference's own gradients
+(tests/golden/train_64.npz, tools/make_golden_train.py).
+
+Tolerances: operators 2e-5 relative L2 (fp32 sums in a different order); whole pictures 2e-3
+on the concatenated gradient and 2e-2 per parameter tensor -- a latent that lands on the other
+side of a rounding boundary (straight-through estimator) changes the gradient discontinuously,
+so per-tensor agreement cannot be tighter than the forward's symbol agreement.
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+pytestmark = pytest.mark.gpu
+
+CONV_CASES = [
+    dict(name="k3s1_act_res", seg_C=(64,), Cout=64, ks=3, stride=1, H=20, W=36, out_slope=0.01, res=True),
+    dict(name="k3s1_plain", seg_C=(64,), Cout=64, ks=3, stride=1, H=20, W=36),
+    dict(name="k3s2_act", seg_C=(64,), Cout=64, ks=3, stride=2, H=20, W=36, out_slope=0.01),
+    dict(name="k1s2", seg_C=(64,), Cout=64, ks=1, stride=2, H=20, W=36),
+    dict(name="k1s1_gate", seg_C=(32, 32), Cout=64, ks=1, stride=1, H=20, W=36, res=True, gate=True),
+    dict(name="k7_relu", seg_C=(8,), Cout=32, ks=7, stride=1, H=24, W=40, out_slope=0.0),
+    dict(name="k7_to2_res", seg_C=(16,), Cout=2, ks=7, stride=1, H=24, W=40, res=True),
+    dict(name="k3_ps_act", seg_C=(64,), Cout=256, ks=3, stride=1, H=12, W=20, out_slope=0.01, ps=True),
+    dict(name="k1_ps", seg_C=(128,), Cout=256, ks=1, stride=1, H=12, W=20, ps=True),
+    dict(name="k3_inact_res2", seg_C=(128,), Cout=64, ks=3, stride=1, H=12, W=20, in_slope=0.1, out_slope=0.1, res=True,
+         res2=True),
+    dict(name="k3_seg3", seg_C=(64, 64, 96), Cout=96, ks=3, stride=1, H=8, W=12, out_slope=0.2),
+    dict(name="k3_cinslice", seg_C=(128,), Cout=192, ks=3, stride=1, H=8, W=12, out_slope=0.2, cin_slice=(0, 128, 192)),
+    dict(name="k3_3to64", seg_C=(3,), Cout=64, ks=3, stride=1, H=20, W=36),
+    dict(name="k3_67s2", seg_C=(3, 64), Cout=64, ks=3, stride=2, H=20, W=36),
+    dict(name="k3_64to3", seg_C=(64,), Cout=3, ks=3, stride=1, H=20, W=36),
+    dict(name="k3_odd_size", seg_C=(64,), Cout=64, ks=3, stride=1, H=17, W=45, N=1, out_slope=0.01),
+]
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from vcm_ts_amd.engine import Engine
+
+    return Engine(torch.device("cuda:0"), "fp32")
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=[c["name"] for c in CONV_CASES])
+def test_conv_backward(eng, case):
+    import grad_check as G
+
+    kw = dict(case)
+    name = kw.pop("name")
+    assert G.conv_case(eng, name, kw.pop("seg_C"), kw.pop("Cout"), kw.pop("ks"), kw.pop("stride"), kw.pop("H"),
+                       kw.pop("W"), seed=CONV_CASES.index(case), **kw) < 2e-5
+
+
+def test_resampling_backward(eng):
+    import grad_check as G
+
+    assert G.resample_cases(eng) < 2e-5
+
+
+def test_frame_gradients_match_oracle_autograd():
+    import grad_check as G
+
+    assert G.frame_case(size=64, N=2, second=True, verbose=False) < 2e-3
+
+
+def test_frame_gradients_match_reference_fixture():
+    """HIP path against the numbers the reference itself produced (loss, bpp/mse, every
+    parameter's gradient norm and first values, q-scale gradients)."""
+    from tests.util import golden
+    from vcm_ts_amd.dmc import DMC
+    from vcm_ts_amd.synthetic import frames
+
+    fx = golden("train_64")
+    N, size, lam, me_w = int(fx["meta"][0]), int(fx["meta"][1]), float(fx["meta"][2]), float(fx["meta"][3])
+    dev = torch.device("cuda:0")
+    m = DMC(precision="fp32").to(dev).train()
+    for p in m.parameters():
+        p.requires_grad_(True)
+    fr = frames(3, N * 3, size, size)
+    x0, x1, x2 = (torch.from_numpy(fr[k * N:(k + 1) * N]).to(dev) for k in range(3))
+    q_mv = torch.tensor([1.0, 0.8], device=dev).view(N, 1, 1, 1)
+    q_y = torch.tensor([1.2, 0.9], device=dev).view(N, 1, 1, 1)
+    dpb = {"ref_frame": x0, "ref_feature": None, "ref_y": None, "ref_mv_y": None}
+    params = dict(m.named_parameters())
+    for step, x in enumerate((x1, x2)):
+        p = f"s{step}_"
+        m._noise_override = {k: torch.from_numpy(fx[p + "noise_" + k]) for k in ("y", "mv_y", "z", "mv_z")}
+        m.zero_grad(set_to_none=True)
+        qm, qy = q_mv.clone().requires_grad_(), q_y.clone().requires_grad_()
+        out = m.forward_one_frame(x, dpb, qm, qy)
+        loss = torch.mean(out["bpp"] + lam * out["mse"] + me_w * out["me_mse"])
+        loss.backward()
+        for key in ("bpp_y", "bpp_z", "bpp_mv_y", "bpp_mv_z", "bpp", "mse", "me_mse"):
+            np.testing.assert_allclose(out[key].detach().cpu().numpy(), fx[p + key], rtol=1e-4, err_msg=p + key)
+        assert abs(loss.item() - float(fx[p + "loss"])) <= 1e-4 * abs(float(fx[p + "loss"]))
+        np.testing.assert_allclose(qm.grad.cpu().numpy(), fx[p + "dq_mv"], rtol=5e-3, atol=1e-6)
+        np.testing.assert_allclose(qy.grad.cpu().numpy(), fx[p + "dq_y"], rtol=5e-3, atol=1e-6)
+        names = [str(n) for n in fx[p + "grad_names"]]
+        sq_ref = sq_diff = 0.0
+        for i, name in enumerate(names):
+            want = float(fx[p + "grad_norm"][i])
+            g = params[name].grad
+            if want < 0:
+                assert g is None or float(g.norm()) == 0.0, name
+                continue
+            assert g is not None, name
+            got = float(g.double().norm())
+            assert abs(got - want) <= 2e-2 * want + 1e-8, (name, got, want)
+            head = g.reshape(-1)[:8].cpu().numpy()
+            np.testing.assert_allclose(head, fx[p + "grad_head"][i][: head.size], rtol=0, atol=2e-2 * want + 1e-8,
+                                       err_msg=name)
+            sq_ref += want * want
+            sq_diff += (got - want) ** 2
+        assert sq_diff ** 0.5 <= 2e-3 * sq_ref ** 0.5
+        dpb = {k: v.detach() for k, v in out["dpb"].items()}
+    m._noise_override = None
+
+
+def test_frozen_parameters_get_no_gradient_and_dpb_inputs_get_one():
+    from vcm_ts_amd.dmc import DMC
+    from vcm_ts_amd.synthetic import frames
+
+    dev = torch.device("cuda:0")
+    m = DMC(precision="fp32").to(dev).train()
+    live = [n for n, _ in m.named_parameters() if n.startswith("recon_generation_net.")]
+    for n, p in m.named_parameters():
+        p.requires_grad_(n in live)
+    fr = frames(5, 2, 64, 64)
+    x0, x1 = torch.from_numpy(fr[0:1]).to(dev), torch.from_numpy(fr[1:2]).to(dev)
+    out = m.forward_one_frame(x1, {"ref_frame": x0, "ref_feature": None, "ref_y": None, "ref_mv_y": None}, 1.0, 1.0)
+    (out["bpp"] + 100 * out["mse"]).mean().backward()
+    for n, p in m.named_parameters():
+        if n in live:
+            assert p.grad is not None and torch.isfinite(p.grad).all(), n
+        else:
+            assert p.grad is None, n
+    assert sum(float(p.grad.abs().sum()) for n, p in m.named_parameters() if n in live) > 0
+    # a DPB entry that requires grad is an input of the autograd node (cascade training)
+    dpb = {k: v.detach().clone().requires_grad_() for k, v in out["dpb"].items()}
+    m.zero_grad(set_to_none=True)
+    out2 = m.forward_one_frame(x1, dpb, 1.0, 1.0)
+    (out2["bpp"] + 100 * out2["mse"]).mean().backward()
+    for k, v in dpb.items():
+        assert v.grad is not None and torch.isfinite(v.grad).all() and float(v.grad.abs().sum()) > 0, k

@@ -200,8 +200,19 @@ def test_requires_update_and_padding(nets):
         fresh.compress(x, dpb, 1.0, 1.0)
     with pytest.raises(AssertionError):
         fresh.forward_one_frame(torch.rand(1, 3, 60, 64).cuda(), dpb, 1.0, 1.0)
-    with pytest.raises(RuntimeError):  # training-mode forward (noise + STE) is not built: refuse loudly
-        fresh.train().forward_one_frame(x, dpb, 1.0, 1.0)
+    # the I-picture codec has no training path (the reference trains only DMC and runs IntraNoAR
+    # under no_grad, core/model/dcvc_hem.py:164-167): refuse loudly instead of returning eval numbers
+    from vcm_ts_amd.intra import IntraNoAR
+
+    with pytest.raises(RuntimeError):
+        IntraNoAR().cuda().train()(x, 1.0)
+    # training-mode DMC forward: noisy-latent bit estimate differs from the eval estimate, same distortion
+    ev = fresh(x, dpb, 1.0, 1.0)
+    tr = fresh.train()(x, dpb, 1.0, 1.0)
+    fresh.eval()
+    assert not tr["bpp"].requires_grad and tr["bpp"].shape == (1,) and torch.isfinite(tr["bpp"]).all()
+    torch.testing.assert_close(tr["mse"], ev["mse"], rtol=1e-5, atol=0)
+    assert float((tr["bpp"] - ev["bpp"]).abs()) > 0
 
 
 def test_full_size_properties(nets):

@@ -82,3 +82,81 @@ def test_bench_runs_with_world_size_two():
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
     assert {"roofline", "metric", "unit", "ms_per_step", "config"} <= set(d)
+
+
+DDP_WORKER = r"""
+import os, sys, pickle
+sys.path.insert(0, os.environ["DCVC_ROOT"])
+import numpy as np, torch, torch.distributed as dist
+from vcm_ts_amd.dcvc_hem import build_model, make_cfg
+from vcm_ts_amd.synthetic import frames
+dist.init_process_group("gloo", init_method="env://")
+rank, world = dist.get_rank(), dist.get_world_size()
+dev = torch.device("cuda:0")
+model = build_model(make_cfg(lambdas=(85.0, 380.0)), precision="fp32").to(dev).train()
+model.activate_modules_all()
+g = torch.Generator().manual_seed(7)
+model.dmc._noise_override = {"y": torch.rand(2, 96, 4, 4, generator=g) - 0.5, "mv_y": torch.rand(2, 64, 4, 4, generator=g) - 0.5,
+                             "z": torch.rand(2, 64, 1, 1, generator=g) - 0.5, "mv_z": torch.rand(2, 64, 1, 1, generator=g) - 0.5}
+ddp = torch.nn.parallel.DistributedDataParallel(model, find_unused_parameters=True)   # train_multi.py:179
+opt = torch.optim.SGD(ddp.parameters(), lr=1e-4)
+x = torch.from_numpy(np.stack([frames(70 + 10 * rank + i, 3, 64, 64) for i in range(2)])).to(dev)   # this rank's clip
+before = {k: v.detach().clone() for k, v in model.dmc.named_parameters()}
+dpb = {"ref_frame": x[:, 0], "ref_feature": None, "ref_y": None, "ref_mv_y": None}
+for t in (1, 2):                               # single_step of train_multi.py:203-232, two P pictures
+    opt.zero_grad()
+    r = ddp("single_multi", x[:, t], x[:, t], "mse", ["bpp"], perceptual_loss=False, dpb=dpb)
+    r["loss_to_opt"].backward()
+    if t == 1:
+        grads = {k: v.grad.detach().cpu().clone() for k, v in model.dmc.named_parameters() if v.grad is not None}
+    opt.step()
+    dpb = r["dpb"]
+after = {k: v.detach().cpu() for k, v in model.dmc.named_parameters()}
+out = [None] * world
+dist.all_gather_object(out, (grads, {k: after[k] for k in ("recon_generation_net.recon_conv.weight", "optic_flow.moduleBasic.0.conv1.bias",
+                                                          "y_q_basic", "feature_adaptor_P.weight", "feature_adaptor_I.weight")}))
+if rank == 0:
+    pickle.dump(out, open(os.environ["DCVC_OUT"], "wb"))
+dist.destroy_process_group()
+"""
+
+
+def test_ddp_training_step_averages_gradients_across_ranks(tmp_path):
+    """trainer_multi.py's step with the model wrapped in DistributedDataParallel: after
+    backward every rank holds the mean of the per-rank gradients, and parameters stay identical."""
+    import pickle
+
+    script = os.path.join(tmp_path, "ddp_worker.py")
+    open(script, "w").write(DDP_WORKER)
+    out = os.path.join(tmp_path, "ddp.pkl")
+    r = _run([script], {"DCVC_ROOT": ROOT, "DCVC_OUT": out})
+    assert r.returncode == 0, r.stderr[-3000:]
+    (g0, p0), (g1, p1) = pickle.load(open(out, "rb"))
+    assert set(g0) == set(g1) and "feature_adaptor_I.weight" in g0 and "feature_adaptor_P.weight" not in g0
+    for k in g0:
+        assert torch.equal(g0[k], g1[k]), k                    # all-reduced: identical on both ranks
+    for k in p0:
+        assert torch.isfinite(p0[k]).all() and torch.equal(p0[k], p1[k]), k   # so are the parameters after two steps
+    # the all-reduced gradient is the mean of what each rank computes alone
+    from vcm_ts_amd.dcvc_hem import build_model, make_cfg
+    from vcm_ts_amd.synthetic import frames
+
+    dev = torch.device("cuda:0")
+    model = build_model(make_cfg(lambdas=(85.0, 380.0)), precision="fp32").to(dev).train()
+    model.activate_modules_all()
+    g = torch.Generator().manual_seed(7)
+    model.dmc._noise_override = {"y": torch.rand(2, 96, 4, 4, generator=g) - 0.5, "mv_y": torch.rand(2, 64, 4, 4, generator=g) - 0.5,
+                                 "z": torch.rand(2, 64, 1, 1, generator=g) - 0.5, "mv_z": torch.rand(2, 64, 1, 1, generator=g) - 0.5}
+    acc = {}
+    for rank in (0, 1):
+        x = torch.from_numpy(np.stack([frames(70 + 10 * rank + i, 3, 64, 64) for i in range(2)])).to(dev)
+        model.zero_grad(set_to_none=True)
+        dpb = {"ref_frame": x[:, 0], "ref_feature": None, "ref_y": None, "ref_mv_y": None}
+        res = model("single_multi", x[:, 1], x[:, 1], "mse", ["bpp"], perceptual_loss=False, dpb=dpb)
+        res["loss_to_opt"].backward()
+        for k, v in model.dmc.named_parameters():
+            if v.grad is not None:
+                acc[k] = acc.get(k, 0) + v.grad.detach().cpu() / 2
+    assert set(acc) == set(g0)
+    for k in acc:
+        torch.testing.assert_close(g0[k], acc[k], rtol=1e-4, atol=1e-6 + 1e-5 * float(acc[k].abs().max()), msg=k)

@@ -1,5 +1,7 @@
-"""DCVC_HEM wrapper (vcm_ts_amd/dcvc_hem.py) in evaluation mode against the loss assembly
-restated from /root/reference/core/model/dcvc_hem.py over the CPU oracle's forward_one_frame."""
+"""DCVC_HEM wrapper (vcm_ts_amd/dcvc_hem.py) against the loss assembly restated from
+/root/reference/core/model/dcvc_hem.py over the CPU oracle's forward_one_frame: evaluation
+results, and training steps (backward + optimiser step inside forward) against the oracle's
+autograd gradients."""
 import numpy as np
 import pytest
 import torch
@@ -94,10 +96,70 @@ def test_single_multi_simple_and_perceptual_hook(model):
     torch.testing.assert_close(out[1]["ref_frame"], r["dpb"]["ref_frame"][1:2], rtol=1e-4, atol=1e-5)
 
 
-def test_training_is_refused_and_groups(model):
+def _noise(seed, n=2, size=64):
+    g = torch.Generator().manual_seed(seed)
+    return {"y": torch.rand(n, 96, size // 16, size // 16, generator=g) - 0.5,
+            "mv_y": torch.rand(n, 64, size // 16, size // 16, generator=g) - 0.5,
+            "z": torch.rand(n, 64, size // 64, size // 64, generator=g) - 0.5,
+            "mv_z": torch.rand(n, 64, size // 64, size // 64, generator=g) - 0.5}
+
+
+def _oracle_step_gradients(x, p_frames, rate_keys, dist_key, noise, cascade):
+    """Gradients of the first optimiser step of `single` (one P picture, dcvc_hem.py:189-229) or
+    `cascade` (p_frames pictures chained through an un-detached DPB, :411-471) from the oracle."""
+    from vcm_ts_amd.params import dmc_spec, seeded_state_dict
+
+    w = {k: v.clone().requires_grad_() for k, v in seeded_state_dict(dmc_spec(anchor_num=len(LAMBDAS))).items()}
+    lam = torch.tensor(LAMBDAS)
+    dpb = {"ref_frame": x[:, 0], "ref_feature": None, "ref_y": None, "ref_mv_y": None}
+    losses = []
+    with R.training_mode():
+        for p in range(p_frames if cascade else 1):
+            o = R.dmc_forward_one_frame(w, x[:, 1 + p], dpb, w["mv_y_q_scale"], w["y_q_scale"], noise=noise)
+            dpb = o["dpb"]
+            rate = sum((o[k] for k in rate_keys), torch.zeros(2))
+            losses.append(rate + lam * o[dist_key])
+    torch.stack(losses, -1).mean(-1).mean().backward()
+    return {k: v.grad for k, v in w.items() if v.grad is not None}
+
+
+@pytest.mark.parametrize("method", ["single", "cascade"])
+def test_training_step_inside_forward_matches_oracle_gradients(method):
+    """is_train=True: the wrapper back-propagates and steps the optimiser inside forward.  With
+    plain SGD(lr=1) the parameter change of the first step IS minus the gradient, which must be
+    the oracle's autograd gradient of the same loss -- for `cascade` that includes the gradient
+    flowing from the second picture into the first through the DPB."""
+    from vcm_ts_amd.dcvc_hem import build_model, make_cfg
+
+    model = build_model(make_cfg(lambdas=LAMBDAS, dist_lambda=1.0, pl_lambda=0.0), precision="fp32").cuda().train()
+    model.activate_modules_all()
+    x = _clip(t=3)
+    noise = _noise(5)
+    model.dmc._noise_override = noise
+    before = {k: v.detach().clone() for k, v in model.dmc.named_parameters()}
+    opt = torch.optim.SGD(model.parameters(), lr=1.0)
+    p_frames = 2 if method == "cascade" else 1
+    clip = x[:, :3] if method == "cascade" else x[:, :2]     # exactly one optimiser step
+    r = model(method, clip.cuda(), clip.cuda(), "mse", ["bpp_y", "bpp_mv_y"], p_frames=p_frames, perceptual_loss=False,
+              optimizer=opt, is_train=True)
+    assert r["single_forwards"] == 1 and torch.isfinite(r["loss"]).all() and not r["loss"].requires_grad
+    want = _oracle_step_gradients(x, p_frames, ["bpp_y", "bpp_mv_y"], "mse", noise, cascade=(method == "cascade"))
+    num = den = 0.0
+    for k, v in model.dmc.named_parameters():
+        delta = (before[k] - v.detach()).cpu()
+        if k not in want:
+            assert float(delta.abs().max()) == 0.0, k
+            continue
+        g = want[k]
+        num += float((delta.double() - g.double()).norm() ** 2)
+        den += float(g.double().norm() ** 2)
+        assert float((delta - g).norm()) <= 3e-2 * float(g.norm()) + 1e-7, k
+    assert (num / den) ** 0.5 < 3e-3
+    model.dmc._noise_override = None
+
+
+def test_groups_and_dispatch(model):
     x = _clip(t=2).cuda()
-    with pytest.raises(NotImplementedError):
-        model("single", x, x, "mse", ["bpp"], p_frames=1, perceptual_loss=False, is_train=True)
     with pytest.raises(ValueError):
         model("nope", x)
     model.activate_modules_inter_dist()

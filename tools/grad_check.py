@@ -90,6 +90,7 @@ def conv_case(e, name, seg_C, Cout, ks, stride, H, W, N=2, in_slope=None, out_sl
 def resample_cases(e):
     g = torch.Generator().manual_seed(1)
     N, H, W = 2, 24, 40
+    worst = 0.0
     for C_ in (3, 64):
         src = torch.randn(N, C_, H, W, generator=g)
         flow = torch.randn(N, 2, H, W, generator=g) * 3
@@ -104,7 +105,9 @@ def resample_cases(e):
         e.tape = None
         e.from_nchw(dout.to(dev), tape.grad(ov))
         tape.backward()
-        print(f"warp C={C_}: dsrc={rel(e.to_nchw(tape.grad(sv)), sr.grad):.1e} dflow={rel(e.to_nchw(tape.grad(fv)), fr.grad):.1e}")
+        a, b = rel(e.to_nchw(tape.grad(sv)), sr.grad), rel(e.to_nchw(tape.grad(fv)), fr.grad)
+        worst = max(worst, a, b)
+        print(f"warp C={C_}: dsrc={a:.1e} dflow={b:.1e}")
     x = torch.randn(N, 2, H, W, generator=g)
     for nm, fn, oshape in (("up2", lambda t: R.up2(t) * 2.0, (N, 2, 2 * H, 2 * W)),
                            ("down2", lambda t: R.down2(t) / 2, (N, 2, H // 2, W // 2)),
@@ -125,7 +128,10 @@ def resample_cases(e):
         e.tape = None
         e.from_nchw(dout.to(dev), tape.grad(ov))
         tape.backward()
-        print(f"{nm}: dx={rel(e.to_nchw(tape.grad(xv)), xr.grad):.1e}")
+        a = rel(e.to_nchw(tape.grad(xv)), xr.grad)
+        worst = max(worst, a)
+        print(f"{nm}: dx={a:.1e}")
+    return worst
 
 
 def frame_case(size=64, N=2, second=True, lam=50.0, verbose=True):

@@ -1,0 +1,89 @@
+"""Generate tests/golden/train_64.npz by running the REFERENCE's training-mode forward and
+torch.autograd backward (build container only; see tools/make_golden.py for the import rules).
+
+Two consecutive P pictures of a 64x64 batch-2 clip: the first after an "I picture" (DPB holds
+only ref_frame), the second with the full (detached) DPB -- the reference's `single` training
+recursion (core/model/dcvc_hem.py:189-196).  Stored: the uniform draws add_noise made (so that
+a checker can replay them), every scalar output, the loss and, per parameter, the gradient's
+L2 norm and its first 8 values; gradients of the per-sample q-scales in full.
+
+    python tools/make_golden_train.py
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+
+from refimport import load  # noqa: E402
+from vcm_ts_amd.params import dmc_spec, seeded_state_dict  # noqa: E402
+from vcm_ts_amd.synthetic import frames  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+LAMBDA, ME_WEIGHT = 50.0, 10.0   # loss = mean(bpp + LAMBDA * mse + ME_WEIGHT * me_mse)
+
+
+def main():
+    DMC, _ = load(with_cxx=False)
+    N, size = 2, 64
+    net = DMC(anchor_num=4)
+    net.load_state_dict(seeded_state_dict(dmc_spec()))
+    net.train()
+    fr = frames(3, N * 3, size, size)
+    x0, x1, x2 = (torch.from_numpy(fr[k * N:(k + 1) * N]) for k in range(3))
+    q_mv = torch.tensor([1.0, 0.8]).view(N, 1, 1, 1)
+    q_y = torch.tensor([1.2, 0.9]).view(N, 1, 1, 1)
+    draws = []
+    orig = net.add_noise
+
+    def add_noise(x):
+        out = orig(x)
+        draws.append((out - x).detach().clone())
+        return out
+
+    net.add_noise = add_noise
+    fx = {"meta": np.array([N, size, LAMBDA, ME_WEIGHT], np.float64), "names": np.array(list(dmc_spec().keys()))}
+    dpb = {"ref_frame": x0, "ref_feature": None, "ref_y": None, "ref_mv_y": None}
+    for step, x in enumerate((x1, x2)):
+        torch.manual_seed(100 + step)
+        draws.clear()
+        net.zero_grad(set_to_none=True)
+        qm, qy = q_mv.clone().requires_grad_(), q_y.clone().requires_grad_()
+        out = net.forward_one_frame(x, dpb, qm, qy)
+        loss = torch.mean(out["bpp"] + LAMBDA * out["mse"] + ME_WEIGHT * out["me_mse"])
+        loss.backward()
+        p = f"s{step}_"
+        for key, t in zip(("y", "mv_y", "z", "mv_z"), draws):   # order of the calls at video_model.py:547-550
+            fx[p + "noise_" + key] = t.numpy().astype(np.float32)
+        for key in ("bpp_y", "bpp_z", "bpp_mv_y", "bpp_mv_z", "bpp", "mse", "me_mse"):
+            fx[p + key] = out[key].detach().numpy().astype(np.float64)
+        fx[p + "loss"] = np.float64(loss.item())
+        fx[p + "dq_mv"] = qm.grad.numpy().astype(np.float64)
+        fx[p + "dq_y"] = qy.grad.numpy().astype(np.float64)
+        norms, heads = [], []
+        for name, prm in net.named_parameters():
+            g = prm.grad
+            if g is None:
+                norms.append(-1.0)
+                heads.append(np.zeros(8, np.float32))
+            else:
+                norms.append(g.double().norm().item())
+                h = np.zeros(8, np.float32)
+                flat = g.reshape(-1)[:8].numpy()
+                h[:flat.size] = flat
+                heads.append(h)
+        fx[p + "grad_names"] = np.array([n for n, _ in net.named_parameters()])
+        fx[p + "grad_norm"] = np.array(norms, np.float64)
+        fx[p + "grad_head"] = np.stack(heads)
+        dpb = {k: v.detach() for k, v in out["dpb"].items()}
+        print(f"step {step}: loss {loss.item():.6f}, {sum(n >= 0 for n in norms)} parameter gradients")
+    np.savez_compressed(os.path.join(OUT, "train_64.npz"), **fx)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,6 +1,6 @@
 """``DCVC_HEM`` -- the reference's training/evaluation wrapper around ``DMC``
 (/root/reference/core/model/dcvc_hem.py:10-631, ``build_model`` core/model/__init__.py:9-11),
-evaluation semantics only in this round.
+for evaluation and for training steps.
 
 What is kept: the ``forward(forward_method, ...)`` dispatch (:605-631) with its five methods, the
 loss assembly ``rate + lambda * (dist * dist_lambda + p_dist * pl_lambda)`` (:208, :300, :436,
@@ -9,10 +9,15 @@ loss assembly ``rate + lambda * (dist * dist_lambda + p_dist * pl_lambda)`` (:20
 result dictionaries with their shapes, ``lambdas`` / ``dmc`` attributes, ``state_dict`` keys
 prefixed ``dmc.`` and the ``activate_modules_*`` parameter groups (:23-102).
 
-What is NOT built yet: autograd through the HIP kernels, so
-``is_train=True`` (optimizer stepping inside forward) raises ``NotImplementedError``; the
-detector-based perceptual losses (core/engine/losses.py, out of scope: third-party networks and
-weights) are replaced by a pluggable callable ``perceptual_loss(target, recon) -> (N,)``.
+Training (``is_train=True``): ``self.dmc.forward_one_frame`` in ``.train()`` mode is one autograd
+node whose backward runs the kernels of include/dcvc_hip_grad.h (vcm_ts_amd/grad.py), so
+``loss_to_opt.backward()`` and ``optimizer.step()`` happen inside ``forward`` exactly where the
+reference has them (:224-229, :466-471): once per P picture in ``single``, once per sub-sequence
+with the gradient flowing through the un-detached DPB in ``cascade``; the ``*_multi`` variants
+return ``loss_to_opt`` for the caller (trainer_multi.py) to step.
+
+Not built: the detector-based perceptual losses (core/engine/losses.py, out of scope: third-party
+networks and weights) -- replaced by a pluggable callable ``perceptual_loss(target, recon) -> (N,)``.
 """
 from __future__ import annotations
 
@@ -73,10 +78,14 @@ class DCVC_HEM(nn.Module):
         self._set(lambda n: True, True)
 
     # ------------------------------------------------------------------ shared pieces
-    def _no_training(self, is_train):
+    def _step(self, optimizer, loss_to_opt, is_train):
+        """:224-229 / :466-471."""
         if is_train:
-            raise NotImplementedError("training through the HIP kernels (backward + optimizer step inside forward) is "
-                                      "not built in this round; call with is_train=False")
+            if optimizer is None:
+                raise ValueError("is_train=True needs an optimizer")
+            optimizer.zero_grad()
+            loss_to_opt.backward()
+            optimizer.step()
 
     def _first_dpb(self, input, t_i, i_frame_net, i_frame_q_scales):
         """I-frame initialisation of a sub-sequence (:160-180)."""
@@ -88,7 +97,7 @@ class DCVC_HEM(nn.Module):
                                    for i in range(input.shape[0])], 0)
         return {"ref_frame": ref, "ref_feature": None, "ref_y": None, "ref_mv_y": None}
 
-    def _p_frame(self, frame, target_frame, dpb, loss_dist_key, loss_rate_keys, perceptual_loss):
+    def _p_frame(self, frame, target_frame, dpb, loss_dist_key, loss_rate_keys, perceptual_loss, keep_graph=False):
         """One forward_one_frame plus the loss terms; returns (rate, dist, p_dist, loss, new dpb)."""
         out = self.dmc.forward_one_frame(frame, dpb, self.dmc.mv_y_q_scale, self.dmc.y_q_scale)
         lambdas = self.lambdas if len(loss_rate_keys) else torch.ones_like(self.lambdas)
@@ -103,8 +112,12 @@ class DCVC_HEM(nn.Module):
         else:
             p_dist = torch.zeros_like(self.lambdas)
         loss = rate + lambdas * (dist * self.dist_lambda + p_dist * self.pl_lambda)
-        # the DPB views are recycled two calls later: detach (reference: :195-196) and keep a copy
-        new_dpb = {k: v.detach().clone() for k, v in out["dpb"].items()}
+        if keep_graph and self.dmc.training:   # cascade: the next picture back-propagates into this one (:418)
+            new_dpb = dict(out["dpb"])
+        elif self.dmc.training:                # a recorded forward owns its buffers: detaching is enough (:195-196)
+            new_dpb = {k: v.detach() for k, v in out["dpb"].items()}
+        else:                                  # inference views are recycled two calls later: keep a copy
+            new_dpb = {k: v.detach().clone() for k, v in out["dpb"].items()}
         return rate, dist, p_dist, loss, new_dpb
 
     @staticmethod
@@ -115,7 +128,6 @@ class DCVC_HEM(nn.Module):
     # ------------------------------------------------------------------ forward methods
     def forward_single(self, input, target, optimizer, loss_dist_key, loss_rate_keys, p_frames, perceptual_loss,
                        is_train=True, i_frame_net=None, i_frame_q_scales=None):
-        self._no_training(is_train)
         n, t = input.shape[:2]
         assert 0 < p_frames < t and self.lambdas.shape[0] == n
         res = {k: [] for k in ("rate", "dist", "p_dist", "loss", "loss_seq", "input_seqs", "decod_seqs")}
@@ -126,9 +138,10 @@ class DCVC_HEM(nn.Module):
             for p in range(p_frames):
                 rate, dist, p_dist, loss, dpb = self._p_frame(input[:, t_i + 1 + p], target[:, t_i + 1 + p], dpb,
                                                               loss_dist_key, loss_rate_keys, perceptual_loss)
+                self._step(optimizer, torch.mean(loss), is_train)
                 for k, v in (("rate", rate), ("dist", dist), ("p_dist", p_dist), ("loss", loss)):
-                    res[k].append(v)
-                losses.append(loss)
+                    res[k].append(v.detach() if is_train else v)
+                losses.append(loss.detach() if is_train else loss)
                 res["single_forwards"] += 1
                 ins.append(target[:, t_i + 1 + p])
                 decs.append(dpb["ref_frame"])
@@ -153,7 +166,7 @@ class DCVC_HEM(nn.Module):
         acc = {"rate": [], "dist": [], "p_dist": [], "loss": []}
         for p in range(p_frames):
             rate, dist, p_dist, loss, dpb = self._p_frame(input[:, t_i + 1 + p], target[:, t_i + 1 + p], dpb,
-                                                          loss_dist_key, loss_rate_keys, perceptual_loss)
+                                                          loss_dist_key, loss_rate_keys, perceptual_loss, keep_graph=True)
             for k, v in (("rate", rate), ("dist", dist), ("p_dist", p_dist), ("loss", loss)):
                 acc[k].append(v)
             ins.append(target[:, t_i + 1 + p])
@@ -163,7 +176,6 @@ class DCVC_HEM(nn.Module):
 
     def forward_cascade(self, input, target, optimizer, loss_dist_key, loss_rate_keys, p_frames, perceptual_loss,
                         is_train=True, i_frame_net=None, i_frame_q_scales=None):
-        self._no_training(is_train)
         n, t = input.shape[:2]
         assert 0 < p_frames < t and self.lambdas.shape[0] == n
         res = {k: [] for k in ("rate", "dist", "p_dist", "loss", "input_seqs", "decod_seqs")}
@@ -172,11 +184,12 @@ class DCVC_HEM(nn.Module):
             dpb = self._first_dpb(input, t_i, i_frame_net, i_frame_q_scales)
             means, ins, decs, _ = self._cascade_span(input, target, dpb, t_i, p_frames, loss_dist_key, loss_rate_keys,
                                                      perceptual_loss)
+            self._step(optimizer, torch.mean(means["loss"]), is_train)
             for k in ("rate", "dist", "p_dist", "loss"):
-                res[k].append(means[k])
+                res[k].append(means[k].detach() if is_train else means[k])
             res["single_forwards"] += 1
             res["input_seqs"].append(ins)
-            res["decod_seqs"].append(decs)
+            res["decod_seqs"].append(decs.detach())
         for k in ("rate", "dist", "p_dist", "loss"):
             res[k] = torch.stack(res[k], -1)
         res["loss_seq"] = res["loss"]

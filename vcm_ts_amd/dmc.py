@@ -15,9 +15,11 @@ src/models/common_model.py:14-217):
 
 Differences that are deliberate and documented in DESIGN.md: tensors in the returned DPB
 are zero-copy logical-NCHW views over channels-last device buffers that the next call
-recycles (two alternating sets); inference only (no autograd through the HIP kernels in
-this round); ``compress`` also returns the key ``"dpb"`` next to the reference's misspelt
-``"dbp"``.
+recycles (two alternating sets; in ``.train()`` mode every call owns fresh buffers instead);
+``compress`` also returns the key ``"dpb"`` next to the reference's misspelt ``"dbp"``.
+
+Training: in ``.train()`` mode ``forward_one_frame`` is one torch.autograd node (``_FrameFn``)
+whose backward runs the gradient kernels of include/dcvc_hip_grad.h through vcm_ts_amd/grad.py.
 """
 from __future__ import annotations
 
@@ -128,11 +130,12 @@ class CodecBase(nn.Module):
         return self
 
     def _eval_only(self):
-        """The reference's training-mode forward adds uniform noise to the latents for the bit
-        estimate and uses a straight-through round (common_model.py:38-49, video_model.py:546-550);
-        neither that nor backward is built yet, so refuse rather than silently return eval numbers."""
+        """IntraNoAR only: the reference never trains the I-picture codec on this path (it runs under
+        no_grad, core/model/dcvc_hem.py:164-167), so a training-mode forward (noisy latents,
+        straight-through round, common_model.py:38-49) is refused rather than silently returning
+        eval numbers.  DMC has a training path (DMC._forward_train)."""
         if self.training:
-            raise RuntimeError("training-mode forward is not built on the HIP path in this round: call .eval() first")
+            raise RuntimeError("IntraNoAR has no training-mode forward on the HIP path: call .eval() first")
 
     def _qvec(self, q, N, default_param=None):
         """q-scale argument (None | float | 0-d / (N,1,1,1) tensor) -> (N,) fp32 device tensor."""
@@ -315,36 +318,47 @@ class _FrameFn(torch.autograd.Function):
     """One P picture as a single autograd node: forward records a grad.Tape on the HIP engine,
     backward replays it with the kernels of include/dcvc_hip_grad.h.  Inputs after the q-scales
     are all parameters of the model, so optimisers, DDP hooks and requires_grad switches
-    (DCVC_HEM.activate_modules_*) work as they do on the reference's nn.Modules."""
+    (DCVC_HEM.activate_modules_*) work as they do on the reference's nn.Modules; the four DPB
+    tensors are inputs and outputs of the node, so a DPB that is not detached carries the
+    gradient into the previous picture (the reference's cascade training modes)."""
+
+    DPB_KEYS = ("ref_frame", "ref_feature", "ref_y", "ref_mv_y")
 
     @staticmethod
-    def forward(ctx, model, x, dpb, qm, qy, *params):
+    def forward(ctx, model, x, rf, rfeat, ry, rmv, qm, qy, *params):
         from .grad import Tape
 
         tape = Tape(model.engine())
-        o, sums = model._train_frame(tape, x.detach(), {k: (None if v is None else v.detach()) for k, v in dpb.items()},
+        dpb_in = dict(zip(_FrameFn.DPB_KEYS, (rf, rfeat, ry, rmv)))
+        tape.dpb_grad = {k for k, need in zip(_FrameFn.DPB_KEYS, ctx.needs_input_grad[2:6]) if need}
+        o, sums = model._train_frame(tape, x.detach(), {k: (None if v is None else v.detach()) for k, v in dpb_in.items()},
                                      qm.detach(), qy.detach())
         ctx.tape, ctx.model, ctx.params = tape, model, params
         ctx.q_shapes = (qm.shape, qy.shape)
+        ctx.out_views = (o["recon"], o["feature"], o["y_hat"], o["mv_y_hat"])
+        ctx.in_views = tuple(o["dv"][k] for k in _FrameFn.DPB_KEYS)
         d = model._dpb_out(o)
-        outs = (sums["bits_mv_y"], sums["bits_mv_z"], sums["bits_y"], sums["bits_z"], sums["sq"], sums["me_sq"],
+        return (sums["bits_mv_y"], sums["bits_mv_z"], sums["bits_y"], sums["bits_z"], sums["sq"], sums["me_sq"],
                 d["ref_frame"], d["ref_feature"], d["ref_y"], d["ref_mv_y"])
-        ctx.mark_non_differentiable(*outs[6:])
-        return outs
 
     @staticmethod
-    def backward(ctx, g_mv_y, g_mv_z, g_y, g_z, g_sq, g_me, *_):
+    def backward(ctx, g_mv_y, g_mv_z, g_y, g_z, g_sq, g_me, *g_dpb):
         tape = ctx.tape
         if tape is None:
             raise RuntimeError("this frame's tape was already consumed (retain_graph is not supported)")
+        e = tape.e
         for name, g in (("bits_mv_y", g_mv_y), ("bits_mv_z", g_mv_z), ("bits_y", g_y), ("bits_z", g_z), ("sq", g_sq),
                         ("me_sq", g_me)):
             if g is not None:
                 tape.up[name] = g.detach().to(torch.float32).contiguous()
+        for v, g in zip(ctx.out_views, g_dpb):  # gradient arriving from the next picture through the DPB
+            if g is not None:
+                e.from_nchw(g, tape.grad(v))
         tape.backward()
         grads = []
-        for p, need in zip(ctx.params, ctx.needs_input_grad[5:]):
-            grads.append(tape.pgrads.get(id(p)) if need else None)
+        for p, need in zip(ctx.params, ctx.needs_input_grad[8:]):
+            g = tape.pgrads.get(id(p)) if need else None
+            grads.append(torch.zeros_like(p) if (need and g is None) else g)
 
         def qgrad(key, shape, need):
             if not need:
@@ -355,10 +369,14 @@ class _FrameFn(torch.autograd.Function):
                 n *= s_
             return (g.sum() if n == 1 else g).reshape(shape)
 
-        gqm = qgrad("mv", ctx.q_shapes[0], ctx.needs_input_grad[3])
-        gqy = qgrad("y", ctx.q_shapes[1], ctx.needs_input_grad[4])
+        gqm = qgrad("mv", ctx.q_shapes[0], ctx.needs_input_grad[6])
+        gqy = qgrad("y", ctx.q_shapes[1], ctx.needs_input_grad[7])
+        g_in = []
+        for v, need in zip(ctx.in_views, ctx.needs_input_grad[2:6]):
+            gv = tape.grad(v, create=False) if (need and v is not None) else None
+            g_in.append(None if gv is None else e.to_nchw(gv))
         ctx.tape = None
-        return (None, None, None, gqm, gqy, *grads)
+        return (None, None, *g_in, gqm, gqy, *grads)
 
 
 class DMC(CodecBase):
@@ -423,12 +441,13 @@ class DMC(CodecBase):
         # current frame lives in channels 0-2 of SpyNet's finest 8-channel input buffer
         spy0 = e.buf("dmc/spy.in0", N, H, W, 8)
         x3 = e.from_nchw(x, spy0.slice(0, 3))
-        if tape is not None:  # pictures and (detached) DPB entries carry no gradient
+        if tape is not None:  # pictures and detached DPB entries carry no gradient
             tape.mark_const(x3)
-            for v in dv.values():
-                tape.mark_const(v)
+            for key, v in dv.items():
                 if v is not None:
                     tape.keep.append(v.base)
+                    if key not in getattr(tape, "dpb_grad", ()):
+                        tape.mark_const(v)
         est_mv = net.spynet(x3, dv["ref_frame"])
         mv_y_raw = net.encoder_stack("mv_encoder", est_mv)
         mv_y = e.scale_channels(mv_y_raw, net.buf("mv_y", like=mv_y_raw, C=64), self.P("mv_y_q_basic").reshape(-1), q_mv,
@@ -523,15 +542,17 @@ class DMC(CodecBase):
             e.tape = None
 
     def _forward_train(self, x, dpb, mv_y_q_scale, y_q_scale):
-        if any(dpb.get(k) is not None and dpb[k].requires_grad for k in ("ref_frame", "ref_feature", "ref_y", "ref_mv_y")):
-            raise NotImplementedError("gradients through the DPB (the reference's cascade training modes) are not built "
-                                      "yet: detach the DPB entries (single / single_multi modes do)")
         qm = self.P("mv_y_q_scale") if mv_y_q_scale is None else mv_y_q_scale
         qy = self.P("y_q_scale") if y_q_scale is None else y_q_scale
         qm = qm if torch.is_tensor(qm) else torch.tensor(float(qm), device=self.device)
         qy = qy if torch.is_tensor(qy) else torch.tensor(float(qy), device=self.device)
-        params = list(self._pmap.values())
-        outs = _FrameFn.apply(self, x, dpb, qm, qy, *params)
+        # only the parameters this picture uses enter the graph (like the reference, where autograd /
+        # DDP's find_unused_parameters see feature_adaptor_I or _P, never both, and a q-scale table
+        # only when it is the one passed in)
+        skip = ("feature_adaptor_P." if dpb.get("ref_feature") is None else "feature_adaptor_I.")
+        params = [p for n, p in self._pmap.items() if not n.startswith(skip) and n not in ("mv_y_q_scale", "y_q_scale")]
+        outs = _FrameFn.apply(self, x, dpb.get("ref_frame"), dpb.get("ref_feature"), dpb.get("ref_y"), dpb.get("ref_mv_y"),
+                              qm, qy, *params)
         bits_mv_y, bits_mv_z, bits_y, bits_z, sq, me_sq, recon, feature, y_hat, mv_y_hat = outs
         pix = x.shape[2] * x.shape[3]
         bpp_y, bpp_z, bpp_mv_y, bpp_mv_z = bits_y / pix, bits_z / pix, bits_mv_y / pix, bits_mv_z / pix
