@@ -134,14 +134,14 @@ def resample_cases(e):
     return worst
 
 
-def frame_case(size=64, N=2, second=True, lam=50.0, verbose=True):
+def frame_case(size=64, N=2, second=True, lam=50.0, verbose=True, precision="fp32"):
     torch.manual_seed(0)
     w0 = seeded_state_dict(dmc_spec())
     fr = frames(3, N * 3, size, size)
     x0 = torch.from_numpy(fr[0:N])
     x1 = torch.from_numpy(fr[N:2 * N])
     x2 = torch.from_numpy(fr[2 * N:3 * N])
-    m = DMC(precision="fp32").to(dev).train()
+    m = DMC(precision=precision).to(dev).train()
     for p in m.parameters():
         p.requires_grad_(True)
     q_mv = torch.tensor([1.0, 0.8][:N]).view(N, 1, 1, 1)
@@ -225,3 +225,5 @@ if __name__ == "__main__":
         resample_cases(e)
     if what in ("all", "frame"):
         frame_case()
+    if what == "frame16":
+        frame_case(precision="fp16x3", verbose=False)

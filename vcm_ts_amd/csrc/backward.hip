@@ -243,18 +243,27 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradK a) {
     }
 }
 
+// Threads walk the partials in their own order (tile, tap, 32x32 element) so the reads of every
+// split are coalesced; four thread groups share the splits of an element.
 __global__ void wgrad_reduce_kernel(const float *__restrict__ scratch, float *__restrict__ dw, int splits, int nct,
                                     int nci, int T, int Cout, int C, int CinT, int cin_offset) {
-    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= (int64_t)Cout * C * T) return;
-    const int t = (int)(gid % T);
-    const int ci = (int)((gid / T) % C);
-    const int co = (int)(gid / ((int64_t)T * C));
-    const int tile = (co >> 5) * nci + (ci >> 5);
-    const int e = (co & 31) * 32 + (ci & 31);
+    __shared__ float sm[256];
+    const int t = threadIdx.x, lane = t & 63, part = t >> 6;
+    const int64_t idx = (int64_t)blockIdx.x * 64 + lane;  // over nct * T * 1024
+    const int64_t total = (int64_t)nct * T * 1024;
     float s = 0.f;
-    for (int k = 0; k < splits; ++k) s += scratch[(((size_t)k * nct + tile) * T + t) * 1024 + e];
-    dw[((size_t)co * CinT + cin_offset + ci) * T + t] += s;
+    if (idx < total)
+        for (int k = part; k < splits; k += 4) s += scratch[(size_t)k * total + idx];
+    sm[t] = s;
+    __syncthreads();
+    if (part == 0 && idx < total) {
+        const float r = (sm[lane] + sm[64 + lane]) + (sm[128 + lane] + sm[192 + lane]);
+        const int e = (int)(idx & 1023);
+        const int tap = (int)((idx >> 10) % T);
+        const int tile = (int)(idx / ((int64_t)T * 1024));
+        const int co = (tile / nci) * 32 + (e >> 5), ci = (tile % nci) * 32 + (e & 31);
+        if (co < Cout && ci < C) dw[((size_t)co * CinT + cin_offset + ci) * T + tap] += r;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -285,20 +294,25 @@ __global__ void channel_dot_partial(const float *__restrict__ a, int a_cs, const
     }
 }
 
+// grid (ceil(C/16), over_batch ? 1 : N): a block finishes 16 channels with 16 interleaved partial
+// sums each, combined in a fixed order
 __global__ void channel_dot_finish(const float *__restrict__ scratch, float *__restrict__ out, int N, int C, int NB,
                                    int over_batch, int accumulate) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
-    if (over_batch) {
-        float s = 0.f;
-        for (int n = 0; n < N; ++n)
-            for (int k = 0; k < NB; ++k) s += scratch[((size_t)n * NB + k) * C + c];
-        out[c] = accumulate ? out[c] + s : s;
-    } else {
-        const int n = blockIdx.y;
-        float s = 0.f;
-        for (int k = 0; k < NB; ++k) s += scratch[((size_t)n * NB + k) * C + c];
-        out[(size_t)n * C + c] = accumulate ? out[(size_t)n * C + c] + s : s;
+    __shared__ float sm[256];
+    const int t = threadIdx.x;
+    const int c = blockIdx.x * 16 + (t & 15), part = t >> 4;
+    const int n0 = over_batch ? 0 : blockIdx.y, n1 = over_batch ? N : n0 + 1;
+    float s = 0.f;
+    if (c < C)
+        for (int n = n0; n < n1; ++n)
+            for (int k = part; k < NB; k += 16) s += scratch[((size_t)n * NB + k) * C + c];
+    sm[t] = s;
+    __syncthreads();
+    if (t < 16 && c < C) {
+        float r = 0.f;
+        for (int k = 0; k < 16; ++k) r += sm[k * 16 + t];
+        float *o = out + (over_batch ? 0 : (size_t)n0 * C) + c;
+        *o = accumulate ? *o + r : r;
     }
 }
 
@@ -816,8 +830,8 @@ extern "C" int dcvc_conv_wgrad(const dcvc_conv_wgrad_args *a, void *stream) {
     else if (a->ks == 1) hipLaunchKernelGGL((wgrad_kernel<1, 2>), grid, dim3(256), 0, st, k);
     else hipLaunchKernelGGL((wgrad_kernel<7, 1>), grid, dim3(256), 0, st, k);
     if (hipGetLastError() != hipSuccess) return DCVC_E_LAUNCH;
-    const int64_t nel = (int64_t)a->Cout * a->C * k.T;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(nblk(nel, 256)), dim3(256), 0, st, a->scratch, a->dw, (int)splits, nct,
+    const int64_t nel = (int64_t)nct * k.T * 1024;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(nblk(nel, 64)), dim3(256), 0, st, a->scratch, a->dw, (int)splits, nct,
                        k.nci, k.T, a->Cout, a->C, a->Cin_total, a->cin_offset);
     RET_LAUNCH();
 }
@@ -832,8 +846,8 @@ extern "C" int dcvc_channel_dot(const float *a, int32_t a_cs, const float *b, in
     NB = NB < 1 ? 1 : (NB > 256 ? 256 : NB);
     hipLaunchKernelGGL(channel_dot_partial, dim3(NB, N, (C + 255) / 256), dim3(256), 0, st, a, a_cs, b, b_cs, scratch, HW,
                        C, NB);
-    hipLaunchKernelGGL(channel_dot_finish, dim3((C + 255) / 256, over_batch ? 1 : N), dim3(256), 0, st, scratch, out, N,
-                       C, NB, over_batch, accumulate);
+    hipLaunchKernelGGL(channel_dot_finish, dim3((C + 15) / 16, over_batch ? 1 : N), dim3(256), 0, st, scratch, out, N, C,
+                       NB, over_batch, accumulate);
     RET_LAUNCH();
 }
 

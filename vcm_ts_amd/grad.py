@@ -39,6 +39,8 @@ class Tape:
         self.pgrads = {}      # id(parameter) -> gradient tensor
         self.q = {}           # qkey -> dict(q_basic param, q_scale tensor, dq_mul, s_div)
         self.up = {}          # name of a per-sample output sum -> upstream gradient (N,) tensor
+        self.pool = []        # zero-filled chunks the gradient buffers are carved from (one memset each)
+        self.pool_left = 0
 
     # ------------------------------------------------------------------ bookkeeping
     def mark_const(self, v: View):
@@ -54,10 +56,25 @@ class Tape:
         if g is None:
             if not create:
                 return None
-            g = torch.zeros(v.N * v.H * v.W * v.cs, dtype=torch.float32, device=self.e.device)
+            g = self.zeros(v.N * v.H * v.W * v.cs)
             self.gbufs[key] = g
         off = (v.ptr - key) // 4
         return View(g, v.C, 0, geom=(v.N, v.H, v.W, v.cs, g.data_ptr() + 4 * off))
+
+    POOL_CHUNK = 64 * 1024 * 1024  # floats
+
+    def zeros(self, n):
+        """n zero floats, 16-byte aligned, from the current chunk (hundreds of gradient buffers per
+        picture would otherwise cost one fill launch each)."""
+        n4 = (n + 3) // 4 * 4
+        if n4 > self.pool_left:
+            size = max(self.POOL_CHUNK, n4)
+            self.pool.append(torch.zeros(size, dtype=torch.float32, device=self.e.device))
+            self.pool_left = size
+        chunk = self.pool[-1]
+        off = chunk.numel() - self.pool_left
+        self.pool_left -= n4
+        return chunk[off : off + n]
 
     def pgrad(self, p: torch.Tensor):
         g = self.pgrads.get(id(p))
