@@ -87,6 +87,77 @@ def cpu_baseline(h, w, threads):
     return dt
 
 
+def train_workload(args, dev, rank, world):
+    """BASELINE configs[2] (N=1) / configs[3] (N>1): a step is forward_one_frame + backward + AdamW on
+    a batch of 4 256x256 pictures per GPU (`single` mode: one optimiser step per P picture,
+    core/model/dcvc_hem.py:189-229), gradients all-reduced by DistributedDataParallel when N>1."""
+    from vcm_ts_amd.dcvc_hem import build_model, make_cfg
+    from vcm_ts_amd.pipeline import timed_region
+
+    batch, size = 4, 256
+    prec = "fp32" if args.precision == "fp32" else "fp16x3"
+    model = build_model(make_cfg(lambdas=(85.0, 170.0, 380.0, 840.0)), precision=prec).to(dev).train()
+    model.activate_modules_all()
+    net = model
+    if world > 1:
+        net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[dev.index] if args.dist_backend == "nccl" else None,
+                                                        find_unused_parameters=True)
+    opt = torch.optim.AdamW(net.parameters(), lr=1e-4)
+    g = torch.Generator().manual_seed(100 + rank)
+    clip = torch.rand(batch, args.warmup + args.steps + 1, 3, size, size, generator=g).to(dev)
+
+    def run(t0, n):
+        dpb = {"ref_frame": clip[:, t0], "ref_feature": None, "ref_y": None, "ref_mv_y": None}
+        for t in range(t0 + 1, t0 + 1 + n):
+            opt.zero_grad()
+            r = net("single_multi", clip[:, t], clip[:, t], "mse", ["bpp"], perceptual_loss=False, dpb=dpb)
+            r["loss_to_opt"].backward()
+            opt.step()
+            dpb = r["dpb"]
+        return float(r["loss_to_opt"].detach())
+
+    run(0, args.warmup)
+    dt, loss = timed_region(lambda: run(args.warmup, args.steps), dev)
+    eng = model.dmc.engine()
+    eng.profile = {}
+    run(0, 1)
+    prof = eng.collect_profile()
+    eng.profile = None
+    dom = prof.get("conv3x3s1", {"flops": 0.0, "ms": 1.0, "launches": 0})
+    peak = PEAK_F32_MFMA_TFLOPS if prec == "fp32" else PEAK_F16_MFMA_TFLOPS / 3.0
+    achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
+    out = {"metric": "trainer step pictures/sec (batch 4 x 256x256 per GPU, bpp+MSE, AdamW)", "value": round(world * batch * args.steps / dt, 2),
+           "unit": "pictures/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "f32" if prec == "fp32" else "f32 (fp16x3 split-MFMA convolutions, fp32 weight gradients)", "data": "synthetic",
+           "config": {"workload": "trainer.py / trainer_multi.py optimiser step (configs[2] at N=1, configs[3] at N>1): "
+                                  "forward_one_frame + backward + AdamW, single mode, uniform-random clips, random-init weights",
+                      "batch_per_gpu": batch, "global_batch": batch * world, "height": size, "width": size, "precision": prec,
+                      "parallelism": f"ddp x{world} ({args.dist_backend})" if world > 1 else "single GPU", "final_loss": round(loss, 4)},
+           "roofline": {"bound": "mfma", "kernel": "conv_mfma<3,1,*> forward + data-gradient launches of one step",
+                        "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
+                        "traffic": None, "launches": dom["launches"]}}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import dcvc_ref as R  # checker timed as the CPU baseline, never on the product path
+        from vcm_ts_amd.params import dmc_spec, seeded_state_dict
+
+        cores = host_cores()
+        torch.set_num_threads(cores)
+        w = {k: v.clone().requires_grad_() for k, v in seeded_state_dict(dmc_spec()).items()}
+        x = clip[:, :2].cpu()
+        noise = {"y": torch.rand(batch, 96, size // 16, size // 16) - 0.5, "mv_y": torch.rand(batch, 64, size // 16, size // 16) - 0.5,
+                 "z": torch.rand(batch, 64, size // 64, size // 64) - 0.5, "mv_z": torch.rand(batch, 64, size // 64, size // 64) - 0.5}
+        t0 = time.time()
+        with R.training_mode():
+            o = R.dmc_forward_one_frame(w, x[:, 1], {"ref_frame": x[:, 0], "ref_feature": None, "ref_y": None, "ref_mv_y": None},
+                                        w["mv_y_q_scale"], w["y_q_scale"], noise=noise)
+        (o["bpp"] + torch.tensor([85.0, 170.0, 380.0, 840.0]) * o["mse"]).mean().backward()
+        sec = time.time() - t0
+        out["cpu_baseline"] = {"value": round(batch / sec, 3), "unit": "pictures/s", "cores": cores, "kind": "port",
+                               "sample": f"1 step (forward + torch.autograd backward, no optimiser) of the oracle on the same batch: {sec:.1f} s"}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -101,6 +172,9 @@ def main():
     ap.add_argument("--precision", default=os.environ.get("DCVC_PRECISION", "fp16x3"), choices=["fp32", "fp16x3"],
                     help="convolution arithmetic: exact fp32 MFMA or split-fp16 MFMA (3 products, fp32 accumulate)")
     ap.add_argument("--cpu-size", type=int, nargs=2, default=None, help="H W of the CPU sample (default: padded full size)")
+    ap.add_argument("--workload", default="encode", choices=["encode", "train"],
+                    help="encode: BASELINE configs[1] (the headline metric, default); train: configs[2]/[3], one optimiser "
+                         "step of trainer.py / trainer_multi.py per bench step (batch 4 of 256x256 per GPU, DDP over RCCL)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -115,6 +189,14 @@ def main():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
     dev = torch.device("cuda", local % torch.cuda.device_count())
     torch.cuda.set_device(dev)
+
+    if args.workload == "train":
+        out = train_workload(args, dev, rank, world)
+        if rank == 0:
+            print(json.dumps(out))
+        if world > 1:
+            dist.destroy_process_group()
+        return
 
     from vcm_ts_amd.dmc import DMC
     from vcm_ts_amd.intra import IntraNoAR

@@ -160,3 +160,12 @@ def test_ddp_training_step_averages_gradients_across_ranks(tmp_path):
     assert set(acc) == set(g0)
     for k in acc:
         torch.testing.assert_close(g0[k], acc[k], rtol=1e-4, atol=1e-6 + 1e-5 * float(acc[k].abs().max()), msg=k)
+
+
+def test_bench_train_workload_with_world_size_two():
+    r = _run([os.path.join(ROOT, "bench.py"), "--workload", "train", "--gpus", "2", "--steps", "2", "--warmup", "1",
+              "--dist-backend", "gloo", "--no-cpu-baseline"], {})
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 8 and line["value"] > 0
+    assert np.isfinite(line["config"]["final_loss"])
