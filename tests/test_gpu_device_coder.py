@@ -1,0 +1,143 @@
+"""Opt-in device entropy coder (include/dcvc_hip_rans.h, vcm_ts_amd/entropy.py DeviceCoder) on a
+real MI355X: the kernels' bytes against the oracle's restatement of the format
+(oracle/drans_py.py: every lane is an ordinary single-stream rANS of the reference's coder),
+round trips incl. escape-coded symbols and ragged lane loads, error flags instead of faults, and
+the codecs' compress / decompress through it (DPB bit-identical to the host-coded path)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import drans_py as D
+from tests.util import golden
+from vcm_ts_amd import entropy as E
+from vcm_ts_amd.synthetic import frames
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def tables():
+    t = golden("tables")
+    return {"scale": (t["dmc_scale_cdf"], t["dmc_scale_len"], t["dmc_scale_off"]),
+            "z": (t["dmc_z_cdf"], t["dmc_z_len"], t["dmc_z_off"])}
+
+
+def _host_lane_encoder(cdf, ln, off):
+    enc = E.BufferedRansEncoder()
+
+    def fn(s, i):  # the product's host coder: byte-identical to oracle/rans_py.py (tests/test_rans.py), but fast
+        enc.reset()
+        enc.encode_with_indexes(np.asarray(s, np.int32), np.asarray(i, np.int32), cdf, ln, off)
+        return enc.flush()
+
+    return fn
+
+
+@pytest.mark.parametrize("n,lanes,spread", [(1000, 64, 3.0), (63, 64, 2.0), (5000, 128, 40.0), (70000, None, 6.0)])
+def test_section_bytes_match_format_oracle_and_round_trip(tables, n, lanes, spread):
+    cdf, ln, off = tables["scale"]
+    rng = np.random.default_rng(n)
+    idx = rng.integers(0, 256, n).astype(np.int32)
+    sym = np.rint(rng.laplace(0, spread, n)).astype(np.int32)
+    sym[::53] = 300          # far beyond every table: sentinel + bypass nibbles
+    sym[7 % n] = -100000
+    dc = E.DeviceCoder(DEV, tables)
+    dc.begin()
+    dc.encode("scale", torch.from_numpy(sym).to(DEV), torch.from_numpy(idx).to(DEV), lanes=lanes)
+    got = dc.end().finish()
+    small = n <= 5000
+    want = D.encode_picture([(sym, idx, cdf, ln, off)], lanes=lanes,
+                            encode_fn=None if small else _host_lane_encoder(cdf, ln, off))
+    assert got == want
+    dc.set_stream(got)
+    out = dc.decode("scale", n, idx=torch.from_numpy(idx).to(DEV), lanes=lanes)
+    dc.check()
+    np.testing.assert_array_equal(out.cpu().numpy(), sym)
+    if small:  # and the oracle's decoder reads the GPU's bytes
+        back, pos = D.decode_section(got, 4, idx, cdf, ln, off)
+        np.testing.assert_array_equal(back, sym)
+        assert pos == len(got)
+
+
+def test_channel_indexed_planes_and_several_sections(tables):
+    cdf, ln, off = tables["z"]
+    rng = np.random.default_rng(3)
+    C_, HW = 64, 12
+    a = np.rint(rng.laplace(0, 2, C_ * HW)).astype(np.int32)
+    b = np.rint(rng.laplace(0, 5, 777)).astype(np.int32)
+    ib = rng.integers(0, 256, 777).astype(np.int32)
+    dc = E.DeviceCoder(DEV, tables)
+    dc.begin()
+    dc.encode("z", torch.from_numpy(a).to(DEV), None, chan=(C_, HW))
+    dc.encode("scale", torch.from_numpy(b).to(DEV), torch.from_numpy(ib).to(DEV))
+    got = dc.end().finish()
+    ia = (np.arange(C_ * HW) // HW) % C_
+    sc = tables["scale"]
+    assert got == D.encode_picture([(a, ia, cdf, ln, off), (b, ib, *sc)])
+    dc.set_stream(got)
+    np.testing.assert_array_equal(dc.decode("z", a.size, chan=(C_, HW)).cpu().numpy(), a)
+    np.testing.assert_array_equal(dc.decode("scale", b.size, idx=torch.from_numpy(ib).to(DEV)).cpu().numpy(), b)
+    dc.check()
+
+
+def test_bad_input_sets_status_instead_of_faulting(tables):
+    dc = E.DeviceCoder(DEV, tables, capacity_words=64)
+    sym = torch.zeros(4096, dtype=torch.int32, device=DEV)
+    idx = torch.zeros(4096, dtype=torch.int32, device=DEV)
+    dc.begin()
+    dc.encode("scale", sym, idx)                      # 64-word payload cannot hold the section
+    with pytest.raises(E.RansError):
+        dc.end().finish()
+    dc = E.DeviceCoder(DEV, tables)
+    dc.begin()
+    dc.encode("scale", sym, idx + 999)                # CDF row out of range
+    with pytest.raises(E.RansError):
+        dc.end().finish()
+    dc.begin()
+    dc.encode("scale", sym, idx)
+    good = dc.end().finish()
+    with pytest.raises(E.RansError):
+        dc.set_stream(b"nope" + good[4:])             # wrong magic
+    dc.set_stream(good[: len(good) // 2 // 4 * 4])    # truncated: flagged, no out-of-bounds read
+    dc.decode("scale", 4096, idx=idx)
+    with pytest.raises(E.RansError):
+        dc.check()
+    dc.set_stream(good)
+    dc.decode("scale", 4000, idx=idx[:4000])          # symbol count differs from the section header
+    with pytest.raises(E.RansError):
+        dc.check()
+
+
+@pytest.mark.parametrize("precision", ["fp32", "fp16x3"])
+def test_codecs_round_trip_through_device_coder(precision):
+    from vcm_ts_amd.dmc import DMC
+    from vcm_ts_amd.intra import IntraNoAR
+    from vcm_ts_amd.pipeline import GopEncoder
+
+    i, d = IntraNoAR(precision=precision).to(DEV).eval(), DMC(precision=precision).to(DEV).eval()
+    fr = frames(21, 4, 128, 192)
+    seq = [torch.from_numpy(fr[t : t + 1]).to(DEV) for t in range(4)]
+    host = GopEncoder(i, d, gop_size=4)
+    coded_h, bits_h, dpb_h = host.encode_gop(seq, 1.0, 1.0, 1.0)
+    ref_h = dpb_h["ref_frame"].clone()
+    dev = GopEncoder(i, d, gop_size=4, coder="device")
+    coded_d, bits_d, dpb_d = dev.encode_gop(seq, 1.0, 1.0, 1.0)
+    assert torch.equal(dpb_d["ref_frame"], ref_h)     # same networks, same symbols: identical reconstruction
+    assert all(p[2][:4] == E.DRANS_MAGIC for p in coded_d) and all(p[2][:4] != E.DRANS_MAGIC for p in coded_h)
+    # the interleaved format costs 12 bytes per lane and 8 per section on top of the same coder
+    assert bits_h < bits_d < bits_h + 8 * 4 * 6 * (12 * 1024 + 8)
+    rec_d = dev.decode_gop(coded_d, 128, 192)          # decode_gop tells the formats apart by the magic
+    rec_h = host.decode_gop(coded_h, 128, 192)
+    for a, b in zip(rec_d, rec_h):
+        assert torch.equal(a, b)
+    assert torch.equal(rec_d[-1], ref_h)
+    # escape-coded symbols through the real pipeline (tiny q-scale => |symbol| far outside the tables)
+    c = d.compress(seq[1], {"ref_frame": seq[0], "ref_feature": None, "ref_y": None, "ref_mv_y": None}, 0.01, 0.01,
+                   coder="device")
+    r = d.decompress({"ref_frame": seq[0], "ref_feature": None, "ref_y": None, "ref_mv_y": None}, c["bit_stream"], 128, 192,
+                     0.01, 0.01)
+    assert torch.equal(r["dpb"]["ref_frame"], c["dpb"]["ref_frame"])
+    with pytest.raises(NotImplementedError):
+        d.compress(torch.cat([seq[1], seq[2]]), {"ref_frame": torch.cat([seq[0], seq[0]]), "ref_feature": None, "ref_y": None,
+                                                 "ref_mv_y": None}, 1.0, 1.0, coder="device")

@@ -106,6 +106,7 @@ class CodecBase(nn.Module):
         self._tables = None
         self._flip = 0
         self._chan_cache, self._stage_bufs, self._stage_flip, self._stage_owner = {}, {}, 0, {}
+        self._dcoder, self._dc_active, self._dc_stream, self._dc_done = None, False, None, None
 
     # -- plumbing ------------------------------------------------------------------------
     def P(self, name):
@@ -235,6 +236,44 @@ class CodecBase(nn.Module):
         self._stage_owner[slot] = pending
         return pending
 
+    # -- opt-in device entropy coder (include/dcvc_hip_rans.h; NOT the reference's wire format) ---
+    def device_coder(self) -> "E.DeviceCoder":
+        if self._tables is None:
+            raise RuntimeError("call update() before compress()/decompress()")
+        if self._dcoder is None or self._dcoder.device != self.device or self._dcoder.tables_id != id(self._tables) \
+                or self._dcoder.symbols_per_lane != self.device_coder_symbols_per_lane:
+            self._dcoder = E.DeviceCoder(self.device, self._tables, symbols_per_lane=self.device_coder_symbols_per_lane)
+            self._dcoder.tables_id = id(self._tables)
+        return self._dcoder
+
+    device_coder_symbols_per_lane = 512  # see include/dcvc_hip_rans.h: payload size vs coder latency
+
+    def _stage_symbols_device(self, planes, batch=1):
+        if batch != 1:
+            raise NotImplementedError("the device coder codes one picture per payload (batch 1)")
+        dc = self.device_coder()
+        # The coder kernels (one workgroup per plane, ~1-2 ms per picture) run on a side stream behind
+        # this picture's kernels, so they overlap the next picture's motion estimation; _wait_coder()
+        # holds the launch stream back only where the symbol buffers are about to be rewritten.
+        main = torch.cuda.current_stream(self.device)
+        if self._dc_stream is None:
+            self._dc_stream = torch.cuda.Stream(self.device)
+        ready = torch.cuda.Event()
+        ready.record(main)
+        self._dc_stream.wait_event(ready)
+        with torch.cuda.stream(self._dc_stream):
+            dc.begin()
+            for table, sym, idx, chan in planes:
+                dc.encode(table, sym, idx, chan=None if idx is not None else (chan[1], chan[2] * chan[3]))
+            pending = dc.end()
+        self._dc_done = pending.event
+        return pending
+
+    def _wait_coder(self):
+        if self._dc_done is not None:
+            torch.cuda.current_stream(self.device).wait_event(self._dc_done)
+            self._dc_done = None
+
     def _encode_factorized(self, name, sym: torch.Tensor, N, C_, H, W):
         cdf, ln, off = self._tables[name]
         s = sym.cpu().numpy()
@@ -246,12 +285,16 @@ class CodecBase(nn.Module):
         self.entropy_coder.encode_with_indexes(sym.cpu().numpy(), idx.cpu().numpy(), cdf, ln, off)
 
     def _decode_factorized(self, name, N, C_, H, W) -> torch.Tensor:
+        if self._dc_active:
+            return self._dcoder.decode(name, N * C_ * H * W, chan=(C_, H * W))
         cdf, ln, off = self._tables[name]
         idx = np.broadcast_to(np.arange(C_, dtype=np.int32)[None, :, None, None], (N, C_, H, W)).reshape(-1)
         out = self.entropy_coder.decoder.decode_stream(idx, cdf, ln, off)
         return torch.from_numpy(out).to(self.device)
 
     def _decode_scale(self, idx: torch.Tensor) -> torch.Tensor:
+        if self._dc_active:
+            return self._dcoder.decode("scale", idx.numel(), idx=idx)
         cdf, ln, off = self._tables["scale"]
         out = self.entropy_coder.decoder.decode_stream(idx.cpu().numpy(), cdf, ln, off)
         return torch.from_numpy(out).to(self.device)
@@ -455,6 +498,7 @@ class DMC(CodecBase):
         mv_z = net.hyper_enc5("mv_hyper_prior_encoder", mv_y)
         mv_z_hat = net.buf("mv_z_hat", like=mv_z, C=64)
         sym_mv_z = e.ibuf("dmc/sym_mv_z", N * 64 * mv_z.HW) if mode == "compress" else None
+        self._wait_coder()  # the previous picture's device coder (if any) has read its symbol planes
         e.round_symbols(mv_z, mv_z_hat, sym_mv_z)
         mv_y_hat, r_mv = self._mv_side(net, dv, mv_y, mv_z_hat, N, q_mv, k, mode)
         mv_hat = net.decoder_stack("mv_decoder", mv_y_hat)
@@ -595,15 +639,17 @@ class DMC(CodecBase):
         return self.forward_one_frame(x, dpb, mv_y_q_scale=mv_y_q_scale, y_q_scale=y_q_scale)
 
     @torch.no_grad()
-    def compress(self, x, dpb, mv_y_q_scale, y_q_scale, defer=False):
-        """defer=True returns {"dpb", "pending"}: call pending.finish() later for the bytes."""
+    def compress(self, x, dpb, mv_y_q_scale, y_q_scale, defer=False, coder="host"):
+        """defer=True returns {"dpb", "pending"}: call pending.finish() later for the bytes.
+        coder="device": opt-in lane-interleaved GPU coder (include/dcvc_hip_rans.h, its own format)."""
         if self.entropy_coder is None:
             raise RuntimeError("call update() before compress()/decompress()")
         o = self._run(x, dpb, mv_y_q_scale, y_q_scale, "compress")
         N = o["N"]  # N > 1: a batch of rate points, one independent stream per element ("bit_streams")
         zm, zz = o["mv_z_hat"], o["z_hat"]
         # bitstream order: mv_z, mv_y step 0, mv_y step 1, z, y step 0, y step 1 (video_model.py:333-340)
-        pending = self._stage_symbols([
+        assert coder in ("host", "device")
+        pending = (self._stage_symbols if coder == "host" else self._stage_symbols_device)([
             ("bit_estimator_z_mv", o["sym_mv_z"], None, (N, 64, zm.H, zm.W)),
             ("scale", o["r_mv"]["sym"][0], o["r_mv"]["idx"][0], None),
             ("scale", o["r_mv"]["sym"][1], o["r_mv"]["idx"][1], None),
@@ -618,9 +664,22 @@ class DMC(CodecBase):
         return {"dbp": d, "dpb": d, "bit_stream": streams[0], "bit_streams": streams, "_views": o}
 
     @torch.no_grad()
-    def decompress(self, dpb, string, height, width, mv_y_q_scale, y_q_scale):
+    def decompress(self, dpb, string, height, width, mv_y_q_scale, y_q_scale, coder=None, defer_check=False):
+        """coder: "host" (reference format), "device" (payloads of compress(coder="device")) or None =
+        tell them apart by the device format's magic.  defer_check (device format only): do not
+        synchronise to read the kernels' status word; the caller calls device_coder().check() later."""
+        self._defer_check = defer_check
         if self.entropy_coder is None:
             raise RuntimeError("call update() before compress()/decompress()")
+        if coder is None:
+            coder = "device" if string[:4] == E.DRANS_MAGIC else "host"
+        self._dc_active = coder == "device"
+        try:
+            return self._decompress(dpb, string, height, width, mv_y_q_scale, y_q_scale)
+        finally:
+            self._dc_active = False
+
+    def _decompress(self, dpb, string, height, width, mv_y_q_scale, y_q_scale):
         e = self.engine()
         net = self._net
         N = 1
@@ -628,7 +687,10 @@ class DMC(CodecBase):
         q_y = self._qvec(y_q_scale, N, "y_q_scale")
         dv = self._views_of_dpb(dpb)
         k = self._out_set(*dv.values())
-        self.entropy_coder.set_stream(string)
+        if self._dc_active:
+            self.device_coder().set_stream(string)
+        else:
+            self.entropy_coder.set_stream(string)
         zh, zw = S.get_downsampled_shape(height, width, 64)
         H, W = zh * 64, zw * 64
         sym = self._decode_factorized("bit_estimator_z_mv", N, 64, zh, zw)
@@ -647,6 +709,10 @@ class DMC(CodecBase):
         feature = net.buf(f"dpb{k}.ref_feature", N=N, H=H, W=W, C=64)
         recon = net.buf(f"dpb{k}.ref_frame", N=N, H=H, W=W, C=3)
         net.recon_generation(dec_feature, c1, feature, recon, clamp=True)  # recon.clamp(0, 1), :413
+        if self._dc_active:
+            self._dcoder.release()
+            if not self._defer_check:
+                self._dcoder.check()  # the one synchronisation of a device-coded picture
         o = dict(recon=recon, feature=feature, y_hat=y_hat, mv_y_hat=mv_y_hat)
         return {"dpb": self._dpb_out(o)}
 
@@ -661,7 +727,7 @@ class DMC(CodecBase):
             bits = S.filesize(output_path) * 8
             t1 = time.time()
             mv_y_q_index, y_q_index, string = S.decode_p(output_path)
-            decoded = self.decompress(dpb, string, pic_height, pic_width, mv_y_q_index / 100, y_q_index / 100)
+            decoded = self.decompress(dpb, string, pic_height, pic_width, mv_y_q_index / 100, y_q_index / 100, coder="host")
             torch.cuda.synchronize(self.device)
             t2 = time.time()
             return {"dpb": decoded["dpb"], "bit": bits, "encoding_time": t1 - t0, "decoding_time": t2 - t1}

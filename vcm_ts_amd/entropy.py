@@ -231,3 +231,174 @@ def factorized_param_block(p):
         rows += [p[f"h{i}"], p[f"b{i}"], p[f"a{i}"]]
     rows += [p["h4"], p["b4"]]
     return torch.stack([r.reshape(-1) for r in rows]).contiguous()
+
+
+# ----------------------------------------------------------------------------- device coder (opt-in)
+DRANS_MAGIC = b"DGR1"
+
+
+class DevicePayload:
+    """Payload of one picture being produced on the device: finish() waits for the size, copies
+    exactly that many bytes to the host and checks the kernels' status word."""
+
+    def __init__(self, coder, buf, size_host, event, cursor_at):
+        self.coder, self.buf, self.size_host, self.event, self.cursor_at = coder, buf, size_host, event, cursor_at
+        self._bytes = None
+        self._streams = None  # same attribute PendingStream uses for "retired"
+
+    def finish(self) -> bytes:
+        if self._bytes is None:
+            self.event.synchronize()
+            words, status = int(self.size_host[self.cursor_at]), int(self.size_host[1])
+            if status:
+                raise RansError(f"device entropy coder status {status} (1 index, 2 space, 4 stream)")
+            self._bytes = self.buf[:words].cpu().numpy().tobytes()
+            self._streams = [self._bytes]
+        return self._bytes
+
+    def finish_all(self):
+        return [self.finish()]
+
+
+class DeviceCoder:
+    """Lane-interleaved rANS on the GPU (include/dcvc_hip_rans.h): the symbol planes are coded where
+    the kernels left them and only the payload crosses PCIe.  Opt-in: the wire format is NOT the
+    reference's (see the header); tables are the same host-built integer CDFs, uploaded once."""
+
+    def __init__(self, device, tables, capacity_words=8 * 1024 * 1024, symbols_per_lane=512):
+        """symbols_per_lane: the size / latency knob of the format (12 bytes per lane, ~1 us per symbol
+        of a lane); encoder and decoder must use the same value."""
+        self.device = torch.device(device)
+        self.symbols_per_lane = int(symbols_per_lane)
+        self.L = lib.hip()
+        self.t = {}
+        for name, (cdf, ln, off) in tables.items():
+            cdf, ln = np.ascontiguousarray(cdf, np.int32), np.ascontiguousarray(ln, np.int32)
+            lut = np.empty((cdf.shape[0], 256), np.uint8)
+            lib.check(self.L.dcvc_drans_build_lut(cdf.ctypes.data, cdf.shape[0], cdf.shape[1], ln.ctypes.data, lut.ctypes.data),
+                      "drans_build_lut")
+            c = torch.from_numpy(cdf).to(self.device)
+            self.t[name] = (c, torch.from_numpy(ln).to(self.device),
+                            torch.from_numpy(np.ascontiguousarray(off, np.int32)).to(self.device), c.shape[0], c.shape[1],
+                            torch.from_numpy(lut).to(self.device))
+        # two payload buffers: picture t+1 may be enqueued before picture t's bytes are fetched
+        self.payloads = [torch.empty(capacity_words, dtype=torch.int32, device=self.device) for _ in range(2)]
+        self.payload = self.payloads[0]
+        # [cursor A, status, cursor B]: every launch reads one cursor and writes the other (its lanes are
+        # spread over several workgroups); `sel` is the index of the cursor that is current
+        self.state = torch.zeros(3, dtype=torch.int32, device=self.device)
+        self.sel = 0
+        self.state_host = [torch.zeros(3, dtype=torch.int32).pin_memory() for _ in range(2)]
+        self.init_host = torch.tensor([1, 0, 1], dtype=torch.int32).pin_memory()
+        self.magic = torch.tensor([int.from_bytes(DRANS_MAGIC, "little")], dtype=torch.int32).pin_memory()
+        self.flip = 0
+        self.scratch = None
+        self.words = 0
+
+    def lanes_for(self, n):
+        if self.symbols_per_lane == 512:
+            return int(self.L.dcvc_drans_default_lanes(n))
+        lanes = (-(-n // self.symbols_per_lane) + 63) // 64 * 64
+        return max(64, min(8192, lanes))
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    # -- encoder
+    def _cursors(self):
+        """(pointer to the current cursor, pointer to the one the next launch writes); flips."""
+        a = self.state.data_ptr() + 8 * self.sel
+        self.sel ^= 1
+        return a, self.state.data_ptr() + 8 * self.sel
+
+    def begin(self):
+        self.payload = self.payloads[self.flip]
+        self.payload[:1].copy_(self.magic, non_blocking=True)
+        self.state.copy_(self.init_host, non_blocking=True)
+        self.sel = 0
+
+    def encode(self, table, sym: torch.Tensor, idx=None, chan=None, lanes=None):
+        cdf, ln, off, rows, stride, _ = self.t[table]
+        n = sym.numel()
+        lanes = lanes or self.lanes_for(n)
+        need = int(self.L.dcvc_drans_scratch_words(n, lanes))
+        if self.scratch is None or self.scratch.numel() < need:
+            self.scratch = torch.empty(need, dtype=torch.int32, device=self.device)
+        chw, cc = (0, 0) if chan is None else (chan[1], chan[0])
+        lib.check(self.L.dcvc_drans_encode(sym.data_ptr(), idx.data_ptr() if idx is not None else None, chw, cc, n,
+                                           cdf.data_ptr(), rows, stride, ln.data_ptr(), off.data_ptr(), lanes,
+                                           self.scratch.data_ptr(), self.scratch.numel(), self.payload.data_ptr(),
+                                           self.payload.numel(), *self._cursors(), self.state.data_ptr() + 4,
+                                           self._stream()), "drans_encode")
+
+    def end(self) -> DevicePayload:
+        host = self.state_host[self.flip]
+        self.flip ^= 1
+        host.copy_(self.state, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device))
+        return DevicePayload(self, self.payload, host, ev, 2 * self.sel)
+
+    # -- decoder
+    DEC_SLOTS = 4
+
+    def set_stream(self, data: bytes):
+        """Upload a payload through a pinned staging buffer on a copy stream, so a decoder that defers
+        its status check (decompress(..., defer_check=True)) never blocks the host on the GPU."""
+        if len(data) < 4 or data[:4] != DRANS_MAGIC or len(data) % 4:
+            raise RansError("not a device-coder payload (magic DGR1 missing)")
+        words = len(data) // 4
+        if not hasattr(self, "dec"):
+            self.dec = [dict(dev=None, pin=None, h2d=None, free=None) for _ in range(self.DEC_SLOTS)]
+            self.dec_flip = 0
+            self.copy_stream = torch.cuda.Stream(self.device)
+            self.one_host = torch.tensor([1], dtype=torch.int32).pin_memory()
+        k = self.dec_flip
+        self.dec_flip = (k + 1) % self.DEC_SLOTS
+        d = self.dec[k]
+        if d["h2d"] is not None:
+            d["h2d"].synchronize()          # the staging buffer's previous upload has left the host
+        if d["pin"] is None or d["pin"].numel() < words:
+            cap = max(words, 1 << 20)
+            d["pin"] = torch.empty(cap, dtype=torch.int32).pin_memory()
+            # allocated ON the copy stream: a block the caching allocator recycles from the launch
+            # stream may still be written by kernels the host has run ahead of, and the copy stream
+            # does not wait for those
+            with torch.cuda.stream(self.copy_stream):
+                d["dev"] = torch.empty(cap, dtype=torch.int32, device=self.device)
+        d["pin"][:words].copy_(torch.frombuffer(bytearray(data), dtype=torch.int32))
+        main = torch.cuda.current_stream(self.device)
+        if d["free"] is not None:
+            self.copy_stream.wait_event(d["free"])   # kernels that read this slot's previous payload are done
+        with torch.cuda.stream(self.copy_stream):
+            d["dev"][:words].copy_(d["pin"][:words], non_blocking=True)
+            d["h2d"] = torch.cuda.Event()
+            d["h2d"].record(self.copy_stream)
+        main.wait_event(d["h2d"])
+        self.payload, self.words, self.cur = d["dev"], words, d
+        self.state[:1].copy_(self.one_host, non_blocking=True)   # cursor behind the magic; status stays sticky
+        self.sel = 0
+
+    def release(self):
+        """Call after the last decode() of a payload: its slot may be overwritten once they have run."""
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device))
+        self.cur["free"] = ev
+
+    def decode(self, table, n, idx=None, chan=None, lanes=None) -> torch.Tensor:
+        cdf, ln, off, rows, stride, lut = self.t[table]
+        lanes = lanes or self.lanes_for(n)
+        out = torch.empty(n, dtype=torch.int32, device=self.device)
+        chw, cc = (0, 0) if chan is None else (chan[1], chan[0])
+        lib.check(self.L.dcvc_drans_decode(self.payload.data_ptr(), self.words, *self._cursors(),
+                                           idx.data_ptr() if idx is not None else None, chw, cc, n, cdf.data_ptr(), rows,
+                                           stride, ln.data_ptr(), off.data_ptr(), lut.data_ptr(), lanes, out.data_ptr(),
+                                           self.state.data_ptr() + 4, self._stream()), "drans_decode")
+        return out
+
+    def check(self):
+        """Synchronising: raise if any decode launch since the last check() flagged bad input."""
+        status = int(self.state[1].item())
+        if status:
+            self.state[1:2].zero_()
+            raise RansError(f"device entropy coder status {status} (1 index, 2 space, 4 stream)")

@@ -13,6 +13,7 @@ import time
 
 import torch
 
+from . import entropy as E
 from . import stream as S
 from .dmc import CodecBase
 from .params import intra_spec
@@ -53,6 +54,7 @@ class IntraNoAR(CodecBase):
         z = net.hyper_enc5("hyper_enc", y)
         z_hat = net.buf("z_hat", like=z, C=self.N)
         sym_z = e.ibuf("intra/sym_z", Nb * self.N * z.HW) if mode == "compress" else None
+        self._wait_coder()
         e.round_symbols(z, z_hat, sym_z)
         fusion = net.three_convs("y_prior_fusion", net.hyper_dec("hyper_dec", z_hat))
         y_hat = net.buf("y_hat", like=y, C=self.N)
@@ -74,13 +76,13 @@ class IntraNoAR(CodecBase):
                 "bpp": bpp_y + bpp_z, "bpp_y": bpp_y, "bpp_z": bpp_z, "_views": o}
 
     @torch.no_grad()
-    def compress(self, x, q_scale, defer=False):
+    def compress(self, x, q_scale, defer=False, coder="host"):
         if self.entropy_coder is None:
             raise RuntimeError("call update() before compress()/decompress()")
         o = self._run(x, q_scale, "compress")
-        assert o["N"] == 1
+        assert o["N"] == 1 and coder in ("host", "device")
         zs = o["z_hat"]
-        pending = self._stage_symbols([  # image_model.py:168-171
+        pending = (self._stage_symbols if coder == "host" else self._stage_symbols_device)([  # image_model.py:168-171
             ("bit_estimator_z", o["sym_z"], None, (1, self.N, zs.H, zs.W)),
             ("scale", o["r"]["sym"][0], o["r"]["idx"][0], None),
             ("scale", o["r"]["sym"][1], o["r"]["idx"][1], None),
@@ -90,13 +92,26 @@ class IntraNoAR(CodecBase):
         return {"bit_stream": pending.finish(), "x_hat": o["x_hat"].nchw(), "_views": o}
 
     @torch.no_grad()
-    def decompress(self, bit_stream, height, width, q_scale):
+    def decompress(self, bit_stream, height, width, q_scale, coder=None, defer_check=False):
+        self._defer_check = defer_check
         if self.entropy_coder is None:
             raise RuntimeError("call update() before compress()/decompress()")
+        if coder is None:
+            coder = "device" if bit_stream[:4] == E.DRANS_MAGIC else "host"
+        self._dc_active = coder == "device"
+        try:
+            return self._decompress(bit_stream, height, width, q_scale)
+        finally:
+            self._dc_active = False
+
+    def _decompress(self, bit_stream, height, width, q_scale):
         e = self.engine()
         net = self._net
         q = self._qvec(q_scale, 1, "q_scale")
-        self.entropy_coder.set_stream(bit_stream)
+        if self._dc_active:
+            self.device_coder().set_stream(bit_stream)
+        else:
+            self.entropy_coder.set_stream(bit_stream)
         zh, zw = S.get_downsampled_shape(height, width, 64)
         sym = self._decode_factorized("bit_estimator_z", 1, self.N, zh, zw)
         z_hat = e.symbols_to_nhwc(sym, net.buf("z_hat", N=1, H=zh, W=zw, C=self.N))
@@ -104,6 +119,10 @@ class IntraNoAR(CodecBase):
         y_hat = net.buf("y_hat", N=1, H=zh * 4, W=zw * 4, C=self.N)
         self._dual_prior_decode("y", fusion, "y_spatial_prior", y_hat, self.P("q_basic").reshape(-1), q)
         x_hat = self._synthesis(net, y_hat, 1, zh * 64, zw * 64, clamp=True)  # .clamp_(0, 1), :199
+        if self._dc_active:
+            self._dcoder.release()
+            if not self._defer_check:
+                self._dcoder.check()
         return {"x_hat": x_hat.nchw()}
 
     def encode_decode(self, x, q_scale, output_path=None, pic_width=None, pic_height=None):
@@ -117,7 +136,7 @@ class IntraNoAR(CodecBase):
         bit = S.filesize(output_path) * 8
         t1 = time.time()
         height, width, q_index, bit_stream = S.decode_i(output_path)
-        decompressed = self.decompress(bit_stream, height, width, q_index / 100)
+        decompressed = self.decompress(bit_stream, height, width, q_index / 100, coder="host")
         torch.cuda.synchronize(self.device)
         t2 = time.time()
         return {"bit": bit, "x_hat": decompressed["x_hat"], "encoding_time": t1 - t0, "decoding_time": t2 - t1}

@@ -162,9 +162,14 @@ _SIGS = {
     "dcvc_scale_bits_bwd": [vp, vp, vp, vp, vp, i32, i64, vp],
     "dcvc_factorized_bits_bwd": [vp, i32, vp, vp, vp, i32, vp, i32, i32, i32, vp],
     "dcvc_sq_err_bwd": [vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, vp],
+    # include/dcvc_hip_rans.h
+    "dcvc_drans_encode": [vp, vp, i32, i32, i64, vp, i32, i32, vp, vp, i32, vp, i64, vp, i64, vp, vp, vp, vp],
+    "dcvc_drans_decode": [vp, i64, vp, vp, vp, i32, i32, i64, vp, i32, i32, vp, vp, vp, i32, vp, vp, vp],
+    "dcvc_drans_build_lut": [vp, i32, i32, vp, vp],
 }
 
-HIP_SYMBOLS = sorted(list(_SIGS) + ["dcvc_conv_pack_size", "dcvc_hip_version", "dcvc_conv_wgrad_scratch_min"])
+HIP_SYMBOLS = sorted(list(_SIGS) + ["dcvc_conv_pack_size", "dcvc_hip_version", "dcvc_conv_wgrad_scratch_min",
+                                    "dcvc_drans_default_lanes", "dcvc_drans_scratch_words"])
 RANS_SYMBOLS = [
     "dcvc_rans_encoder_create", "dcvc_rans_encoder_destroy", "dcvc_rans_encoder_reset",
     "dcvc_rans_encoder_encode_with_indexes", "dcvc_rans_encoder_flush_bound", "dcvc_rans_encoder_flush",
@@ -186,6 +191,10 @@ def hip():
         L.dcvc_hip_version.restype = C.c_char_p
         L.dcvc_conv_wgrad_scratch_min.argtypes = [i32, i32, i32]
         L.dcvc_conv_wgrad_scratch_min.restype = i64
+        L.dcvc_drans_default_lanes.argtypes = [i64]
+        L.dcvc_drans_default_lanes.restype = i32
+        L.dcvc_drans_scratch_words.argtypes = [i64, i32]
+        L.dcvc_drans_scratch_words.restype = i64
         _hip = L
     return _hip
 

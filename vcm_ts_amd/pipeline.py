@@ -57,8 +57,11 @@ def timed_region(fn, device=None):
 
 
 class GopEncoder:
-    def __init__(self, i_frame_net, p_frame_net, gop_size=32):
-        self.i_net, self.p_net, self.gop = i_frame_net, p_frame_net, int(gop_size)
+    def __init__(self, i_frame_net, p_frame_net, gop_size=32, coder="host"):
+        """coder="device": payloads in the opt-in GPU format of include/dcvc_hip_rans.h (symbol planes
+        never leave the device; decode_gop recognises them by their magic)."""
+        assert coder in ("host", "device")
+        self.i_net, self.p_net, self.gop, self.coder = i_frame_net, p_frame_net, int(gop_size), coder
         self.i_net.update()
         self.p_net.update()
 
@@ -86,11 +89,11 @@ class GopEncoder:
         # so the GPU works on t while the CPU codes t-1.  The DPB never leaves the device.
         for t, x in enumerate(frames):
             if t % self.gop == 0:
-                r = self.i_net.compress(x, q_i, defer=True)
+                r = self.i_net.compress(x, q_i, defer=True, coder=self.coder)
                 dpb = {"ref_frame": r["x_hat"], "ref_feature": None, "ref_y": None, "ref_mv_y": None}
                 item = ("I", (qi_idx,), r["pending"], t)
             else:
-                r = self.p_net.compress(x, dpb, q_mv_y, q_y, defer=True)
+                r = self.p_net.compress(x, dpb, q_mv_y, q_y, defer=True, coder=self.coder)
                 dpb = r["dpb"]
                 item = ("P", (qmv_idx, qy_idx), r["pending"], t)
             if on_recon is not None:  # reconstruction == what the decoder will produce (clamped)
@@ -104,12 +107,21 @@ class GopEncoder:
 
     def decode_gop(self, coded, height, width):
         """Inverse of encode_gop (the reference decoder path): returns the list of x_hat."""
-        recs, dpb = [], None
+        from .entropy import DRANS_MAGIC
+
+        recs, dpb, deferred = [], None, set()
         for kind, q, payload in coded:
+            # device-format pictures need no host round trip: enqueue them all, read the status once
+            dev_fmt = payload[:4] == DRANS_MAGIC
+            net = self.i_net if kind == "I" else self.p_net
+            if dev_fmt:
+                deferred.add(net)
             if kind == "I":
-                x_hat = self.i_net.decompress(payload, height, width, q[0] / 100)["x_hat"]
+                x_hat = net.decompress(payload, height, width, q[0] / 100, defer_check=dev_fmt)["x_hat"]
                 dpb = {"ref_frame": x_hat, "ref_feature": None, "ref_y": None, "ref_mv_y": None}
             else:
-                dpb = self.p_net.decompress(dpb, payload, height, width, q[0] / 100, q[1] / 100)["dpb"]
+                dpb = net.decompress(dpb, payload, height, width, q[0] / 100, q[1] / 100, defer_check=dev_fmt)["dpb"]
             recs.append(dpb["ref_frame"].clone())
+        for net in deferred:
+            net.device_coder().check()
         return recs
