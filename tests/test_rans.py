@@ -220,3 +220,32 @@ def test_tables_match_reference():
         np.testing.assert_array_equal(c, fx[f"{tag}_cdf"])
         np.testing.assert_array_equal(l, fx[f"{tag}_len"])
         np.testing.assert_array_equal(o, fx[f"{tag}_off"])
+
+
+def test_device_format_oracle_round_trip_and_lane_streams(laplace_tables):
+    """oracle/drans_py.py (restatement of the opt-in device format, include/dcvc_hip_rans.h): a
+    section's lane streams are ordinary single-stream rANS payloads of the product's host coder, and
+    the section decodes back; the lane-count policy matches the library's."""
+    from oracle import drans_py as D
+
+    cdf, ln, off = laplace_tables
+    rng = np.random.default_rng(11)
+    n, L = 700, 64
+    idx = rng.integers(0, 256, n).astype(np.int32)
+    sym = np.rint(rng.laplace(0, 5, n)).astype(np.int32)
+    sym[::41] = 500
+    sym[3] = -70000
+    sec = D.encode_section(sym, idx, cdf, ln, off, lanes=L)
+    hdr = np.frombuffer(sec[: 8 + 4 * L], np.uint32)
+    assert hdr[0] == n and hdr[1] == L
+    pos = 8 + 4 * L
+    for j in range(L):
+        want = product_encode([(sym[j::L], idx[j::L], cdf, ln, off)])
+        assert sec[pos : pos + len(want)] == want and hdr[2 + j] * 4 == len(want), j
+        pos += len(want)
+    assert pos == len(sec)
+    back, end = D.decode_section(D.MAGIC + sec, 4, idx, cdf, ln, off)
+    np.testing.assert_array_equal(back, sym)
+    assert end == 4 + len(sec)
+    for m in (1, 63, 512, 513, 32640, 391680, 10**7):
+        assert D.default_lanes(m) == lib.hip().dcvc_drans_default_lanes(m), m

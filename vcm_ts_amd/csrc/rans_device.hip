@@ -373,7 +373,7 @@ inline size_t table_lds(int n_cdfs, int stride) { return (((size_t)n_cdfs * stri
 extern "C" int32_t dcvc_drans_default_lanes(int64_t n) {
     int64_t l = (n + 511) / 512;
     l = (l + 63) / 64 * 64;
-    return (int32_t)(l < 64 ? 64 : (l > DCVC_DRANS_MAX_LANES ? DCVC_DRANS_MAX_LANES : l));
+    return (int32_t)(l < 64 ? 64 : (l > 1024 ? 1024 : l));
 }
 
 extern "C" int64_t dcvc_drans_scratch_words(int64_t n, int32_t lanes) {
