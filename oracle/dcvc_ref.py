@@ -12,7 +12,7 @@ PyTorch-CPU fp32 over a ``{name: tensor}`` weight dict, what the reference compu
   /root/reference/DCVC_HEM/src/entropy_models/entropy_models.py (CDF tables, indexes)
 
 each function citing the lines it follows.  PINNING: tests/test_oracle_golden.py checks
-it against fixtures under tests/golden/ that tools/make_golden.py produced by importing
+it against fixtures under tests/golden/ that tests/golden/make_golden.py produced by importing
 the reference itself in the build container with the same name-seeded weights
 (vcm_ts_amd/params.py); see DESIGN.md "Oracle".
 """

@@ -2,7 +2,7 @@
 picture at 1088x1920 through the CPU oracle and through the HIP path in both precision modes."""
 import os, sys, time
 import numpy as np, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from oracle import dcvc_ref as R
 from vcm_ts_amd.dmc import DMC

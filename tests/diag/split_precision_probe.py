@@ -2,7 +2,7 @@
 through the whole oracle network: how far do bpp / mse move from the exact-fp32 oracle?"""
 import os, sys
 import numpy as np, torch, torch.nn.functional as F
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from oracle import dcvc_ref as R
 from vcm_ts_amd.params import dmc_spec, intra_spec, seeded_state_dict

@@ -1,12 +1,12 @@
 """Generate tests/golden/*.npz by running the REFERENCE itself (build container only).
 
-Imports /root/reference's DMC / IntraNoAR on CPU (tools/refimport.py), loads the
+Imports /root/reference's DMC / IntraNoAR on CPU (tests/golden/refimport.py), loads the
 name-seeded weights of vcm_ts_amd/params.py, feeds the seeded frames of
 vcm_ts_amd/synthetic.py and stores small numeric fixtures: scalar outputs, integer
 symbol / index planes, CDF tables, statistics and corner crops of the big tensors.
 Only these numbers are committed; no reference source travels.
 
-    python tools/make_golden.py            # writes tests/golden/
+    python tests/golden/make_golden.py            # writes tests/golden/
 """
 import os
 import struct
@@ -17,7 +17,7 @@ import numpy as np
 import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-ROOT = os.path.dirname(HERE)
+ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, HERE)
 

@@ -1,5 +1,5 @@
 """Generate tests/golden/train_64.npz by running the REFERENCE's training-mode forward and
-torch.autograd backward (build container only; see tools/make_golden.py for the import rules).
+torch.autograd backward (build container only; see tests/golden/make_golden.py for the import rules).
 
 Two consecutive P pictures of a 64x64 batch-2 clip: the first after an "I picture" (DPB holds
 only ref_frame), the second with the full (detached) DPB -- the reference's `single` training
@@ -7,7 +7,7 @@ recursion (core/model/dcvc_hem.py:189-196).  Stored: the uniform draws add_noise
 a checker can replay them), every scalar output, the loss and, per parameter, the gradient's
 L2 norm and its first 8 values; gradients of the per-sample q-scales in full.
 
-    python tools/make_golden_train.py
+    python tests/golden/make_golden_train.py
 """
 import os
 import sys
@@ -16,7 +16,7 @@ import numpy as np
 import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-ROOT = os.path.dirname(HERE)
+ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, HERE)
 

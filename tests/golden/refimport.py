@@ -24,7 +24,7 @@ def load(with_cxx: bool = False):
     if REF not in sys.path:
         sys.path.insert(0, REF)
     if with_cxx:
-        here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        here = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
         d = os.path.join(here, "oracle", "_ref")
         if d not in sys.path:
             sys.path.insert(0, d)

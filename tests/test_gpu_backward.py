@@ -1,7 +1,7 @@
 """Gradient parity of the HIP training path (include/dcvc_hip_grad.h, vcm_ts_amd/grad.py) on a
 real MI355X: per operator against torch's CPU autograd of the same operator, and for whole P
 pictures against (a) the oracle's autograd and (b) the reference's own gradients
-(tests/golden/train_64.npz, tools/make_golden_train.py).
+(tests/golden/train_64.npz, tests/golden/make_golden_train.py).
 
 Tolerances: operators 2e-5 relative L2 (fp32 sums in a different order); whole pictures 2e-3
 on the concatenated gradient and 2e-2 per parameter tensor -- a latent that lands on the other
@@ -16,7 +16,7 @@ import pytest
 import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, os.path.join(ROOT, "tools"))
+sys.path.insert(0, os.path.join(ROOT, "tests", "diag"))
 
 pytestmark = pytest.mark.gpu
 

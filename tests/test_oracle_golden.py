@@ -1,5 +1,5 @@
 """Pins the CPU oracle (oracle/dcvc_ref.py) against fixtures produced by the REFERENCE
-itself (tools/make_golden.py imported /root/reference in the build container)."""
+itself (tests/golden/make_golden.py imported /root/reference in the build container)."""
 import numpy as np
 import pytest
 import torch

@@ -1,6 +1,6 @@
 """The oracle's training-mode forward (straight-through round, noisy latents, LowerBound
 gradients) and its torch.autograd gradients against fixtures produced by the reference itself
-(tools/make_golden_train.py -> tests/golden/train_64.npz).  CPU only."""
+(tests/golden/make_golden_train.py -> tests/golden/train_64.npz).  CPU only."""
 import numpy as np
 import torch
 

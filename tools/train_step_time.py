@@ -18,7 +18,6 @@ ap.add_argument("--warmup", type=int, default=3)
 ap.add_argument("--size", type=int, default=256)
 ap.add_argument("--batch", type=int, default=4)
 ap.add_argument("--precision", default="fp32")
-ap.add_argument("--cpu-oracle", action="store_true", help="also time one oracle (CPU autograd) step")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 lam = (85.0, 170.0, 380.0, 840.0)[: a.batch] if a.batch <= 4 else tuple(85.0 * (i + 1) for i in range(a.batch))
@@ -50,20 +49,4 @@ dt = (time.time() - t0) / a.steps
 out = {"workload": f"trainer step: batch {a.batch} x {a.size}x{a.size}, bpp+MSE, AdamW, single mode", "precision": a.precision,
        "ms_per_step": round(dt * 1e3, 2), "frames_per_s": round(a.batch / dt, 2), "loss": float(r["loss_to_opt"]),
        "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 2**30, 2)}
-if a.cpu_oracle:
-    from oracle import dcvc_ref as R
-    from vcm_ts_amd.params import dmc_spec, seeded_state_dict
-
-    torch.set_num_threads(min(16, os.cpu_count() or 1))
-    w = {k: v.clone().requires_grad_() for k, v in seeded_state_dict(dmc_spec()).items()}
-    x = clip[:, :2].cpu()
-    noise = {"y": torch.rand(a.batch, 96, a.size // 16, a.size // 16) - 0.5, "mv_y": torch.rand(a.batch, 64, a.size // 16, a.size // 16) - 0.5,
-             "z": torch.rand(a.batch, 64, a.size // 64, a.size // 64) - 0.5, "mv_z": torch.rand(a.batch, 64, a.size // 64, a.size // 64) - 0.5}
-    t0 = time.time()
-    with R.training_mode():
-        o = R.dmc_forward_one_frame(w, x[:, 1], {"ref_frame": x[:, 0], "ref_feature": None, "ref_y": None, "ref_mv_y": None},
-                                    w["mv_y_q_scale"], w["y_q_scale"], noise=noise)
-    (o["bpp"] + torch.tensor(lam) * o["mse"]).mean().backward()
-    out["cpu_oracle_ms_per_step"] = round((time.time() - t0) * 1e3, 1)
-    out["cpu_threads"] = torch.get_num_threads()
 print(json.dumps(out))

@@ -180,7 +180,7 @@ def intra_spec(N: int = 192, anchor_num: int = 4) -> Spec:
 
 
 # ----------------------------------------------------------------------------- seeded weights
-# Measured on the reference itself (tools/make_golden.py --probe): gain 1.0 makes every
+# Measured on the reference itself (tests/golden/make_golden.py --probe): gain 1.0 makes every
 # latent collapse to zero symbols, 1.4 overflows (mse ~ 1e3 and growing per frame); at 1.3
 # the latents stay |y| <~ 5 with bpp_y ~ 4-5 and the recursion is stable over a GOP.
 DEFAULT_GAIN = 1.3
