@@ -346,9 +346,27 @@ __global__ __launch_bounds__(256, CLASSIC_WAVES_PER_SIMD) void conv_mfma(const C
             if (a.res_gate) gate = *(const f32x4 *)&a.res_gate[(size_t)img * Cfin + cf];
         }
         __syncthreads();  // main loop's LDS reads are done in every wave
+        // All residual loads of the wave's RPW rows go out first (the registers of the main loop's
+        // prefetch are free now), so their latency is paid once and overlaps the LDS transposes.
+        size_t pix[RPW][NIT];
+        bool ok[RPW][NIT];
+        f32x4 rv[RPW][NIT], rv2[RPW][NIT];
 #pragma unroll
         for (int m = 0; m < RPW; ++m) {
             const int oy = y0 + wave * RPW + m;
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int ox = x0 + it * PPI + pl;
+                ok[m][it] = ch_ok && oy < a.Hout && ox < a.Wout;
+                pix[m][it] = a.ps ? ((size_t)(img * Ho + 2 * oy + dy) * Wo + 2 * ox + dx) : ((size_t)(img * Ho + oy) * Wo + ox);
+                rv[m][it] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                rv2[m][it] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (ok[m][it] && a.res) rv[m][it] = *(const f32x4 *)&a.res[pix[m][it] * a.res_cs + cf];
+                if (ok[m][it] && a.res2) rv2[m][it] = *(const f32x4 *)&a.res2[pix[m][it] * a.res2_cs + cf];
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < RPW; ++m) {
 #pragma unroll
             for (int n = 0; n < NT; ++n)
 #pragma unroll
@@ -357,19 +375,6 @@ __global__ __launch_bounds__(256, CLASSIC_WAVES_PER_SIMD) void conv_mfma(const C
             // the transpose tile is private to this wave and a wave's LDS operations execute in
             // order: draining its own ds_writes is all the synchronisation the reads below need
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            size_t pix[NIT];
-            bool ok[NIT];
-            f32x4 rv[NIT], rv2[NIT];
-#pragma unroll
-            for (int it = 0; it < NIT; ++it) {
-                const int ox = x0 + it * PPI + pl;
-                ok[it] = ch_ok && oy < a.Hout && ox < a.Wout;
-                pix[it] = a.ps ? ((size_t)(img * Ho + 2 * oy + dy) * Wo + 2 * ox + dx) : ((size_t)(img * Ho + oy) * Wo + ox);
-                rv[it] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                rv2[it] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                if (ok[it] && a.res) rv[it] = *(const f32x4 *)&a.res[pix[it] * a.res_cs + cf];
-                if (ok[it] && a.res2) rv2[it] = *(const f32x4 *)&a.res2[pix[it] * a.res2_cs + cf];
-            }
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
                 f32x4 v = *(const f32x4 *)&epi[(it * PPI + pl) * EPI_LD + c4];
@@ -383,9 +388,9 @@ __global__ __launch_bounds__(256, CLASSIC_WAVES_PER_SIMD) void conv_mfma(const C
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = fminf(fmaxf(v[e], 0.f), 1.f);
                 }
-                if (a.res) v = v + (a.res_gate ? rv[it] * gate : rv[it]);
-                if (a.res2) v = rv2[it] + v;
-                if (ok[it]) *(f32x4 *)&a.out[pix[it] * a.out_cs + cf] = v;
+                if (a.res) v = v + (a.res_gate ? rv[m][it] * gate : rv[m][it]);
+                if (a.res2) v = rv2[m][it] + v;
+                if (ok[m][it]) *(f32x4 *)&a.out[pix[m][it] * a.out_cs + cf] = v;
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // reads done before the tile is rewritten
         }
