@@ -266,6 +266,16 @@ def test_folder_encode_decode_round_trip(tmp_path):
         a = np.asarray(Image.open(os.path.join(rec_e, f"im{t + 1:05d}.png")))
         b = np.asarray(Image.open(os.path.join(rec_d, f"im{t + 1:05d}.png")))
         assert a.shape == (100, 150, 3) and np.array_equal(a, b)
+    # the same folder through the opt-in device coder: same containers, same reconstructions
+    bins2, rec_d2 = os.path.join(tmp_path, "bins_dev"), os.path.join(tmp_path, "rec_dec_dev")
+    bits2, _ = run_codec.encode_folder(src, bins2, None, gop=3, q=(1.0, 1.1, 0.9), coder="device")
+    assert len(bits2) == 5 and all(b2 > b1 for b1, b2 in zip(bits, bits2))  # 12 B per lane on top of the same coder
+    assert S.decode_p(os.path.join(bins2, "im00002.bin"))[2][:4] == b"DGR1"
+    assert run_codec.decode_folder(bins2, rec_d2, 100, 150, gop=3) == 5
+    for t in range(5):
+        a = np.asarray(Image.open(os.path.join(rec_d, f"im{t + 1:05d}.png")))
+        b = np.asarray(Image.open(os.path.join(rec_d2, f"im{t + 1:05d}.png")))
+        assert np.array_equal(a, b)
 
 
 def test_batch_of_rate_points_compress(nets):

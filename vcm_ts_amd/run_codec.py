@@ -61,13 +61,14 @@ def _nets(device, precision, i_ckpt=None, p_ckpt=None):
 
 
 def encode_folder(frames_dir, bin_dir, recon_dir=None, gop=32, q=(1.0, 1.0, 1.0), device="cuda:0", precision=None,
-                  i_ckpt=None, p_ckpt=None, max_frames=None):
-    """Returns (bits per frame list, (height, width))."""
+                  i_ckpt=None, p_ckpt=None, max_frames=None, coder="host"):
+    """Returns (bits per frame list, (height, width)).  coder="device": payloads in the opt-in GPU
+    format (include/dcvc_hip_rans.h) inside the same .bin containers; decode_folder reads both."""
     os.makedirs(bin_dir, exist_ok=True)
     if recon_dir:
         os.makedirs(recon_dir, exist_ok=True)
     dev = torch.device(device)
-    enc = GopEncoder(*_nets(dev, precision, i_ckpt, p_ckpt), gop_size=gop)
+    enc = GopEncoder(*_nets(dev, precision, i_ckpt, p_ckpt), gop_size=gop, coder=coder)
     reader = PNGReader(frames_dir)
     size, bits = [None], []
 
@@ -135,6 +136,8 @@ def main():
     e.add_argument("--bins", required=True)
     e.add_argument("--recon")
     e.add_argument("--q", type=float, nargs=3, default=(1.0, 1.0, 1.0), metavar=("I", "MV_Y", "Y"))
+    e.add_argument("--coder", default="host", choices=["host", "device"],
+                   help="host: the reference's bitstream (default); device: opt-in GPU entropy coder, own format")
     d = sub.add_parser("decode")
     d.add_argument("--bins", required=True)
     d.add_argument("--recon", required=True)
@@ -148,7 +151,8 @@ def main():
         p.add_argument("--p-ckpt")
     a = ap.parse_args()
     if a.cmd == "encode":
-        bits, size = encode_folder(a.frames, a.bins, a.recon, a.gop, tuple(a.q), a.device, a.precision, a.i_ckpt, a.p_ckpt)
+        bits, size = encode_folder(a.frames, a.bins, a.recon, a.gop, tuple(a.q), a.device, a.precision, a.i_ckpt, a.p_ckpt,
+                                   coder=a.coder)
         print(f"{len(bits)} pictures, {size[0]}x{size[1]}, {sum(bits)} bits, {sum(bits) / (len(bits) * size[0] * size[1]):.4f} bpp")
     else:
         n = decode_folder(a.bins, a.recon, a.height, a.width, a.gop, a.device, a.precision, a.i_ckpt, a.p_ckpt)
