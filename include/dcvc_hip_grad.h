@@ -88,6 +88,9 @@ typedef struct {
     int32_t Cin_total, cin_offset;
     float *scratch;       /* partial sums; at least dcvc_conv_wgrad_scratch_min floats */
     int64_t scratch_floats;
+    int32_t overwrite;    /* 1: write (=) the dw slice instead of accumulating: no zero fill needed */
+    float *db;            /* optional (Cout): bias gradient = sum of dpre over samples and pixels, written (=)
+                             from the same pass over dpre */
 } dcvc_conv_wgrad_args;
 
 int64_t dcvc_conv_wgrad_scratch_min(int32_t Cout, int32_t C, int32_t ks);

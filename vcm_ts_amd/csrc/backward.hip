@@ -149,6 +149,7 @@ struct WgradK {
     int dpre_cs, zs, Hd, Wd;
     int N, Hin, Win, Ho, Wo, Cout;
     float *scratch;
+    float *bscratch;  // per-split bias-gradient partials [splits][nco][32], or NULL
     int nci;        // 32-channel input tiles
     int ntx, nty;   // spatial tiles
     int T;
@@ -175,6 +176,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradK a) {
     for (int t = 0; t < TG; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    // the workgroups of input tile 0 (and filter row 0 for 7x7) also sum dY over the pixels: the
+    // bias gradient comes out of the same pass instead of a separate reduction over dY
+    const bool do_bias = a.bscratch != nullptr && cit == 0 && grp == 0;
+    float bsum = 0.f;
 
     const int ntiles = a.N * a.nty * a.ntx;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -218,6 +224,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradK a) {
             *(f32x4 *)&xs[p * 32 + q * 4] = v;
         }
         __syncthreads();
+        if (do_bias) {
+#pragma unroll 4
+            for (int p = tid >> 5; p < R * TW; p += 8) bsum += dys[p * 32 + (tid & 31)];
+        }
         const int r = wave;  // one output row of the tile per wave
 #pragma unroll 4
         for (int xp = 0; xp < TW; xp += 2) {
@@ -241,14 +251,37 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradK a) {
         float *dst = a.scratch + (((size_t)blockIdx.x * nct + blockIdx.y) * a.T + (grp * TG + t)) * 1024;
         for (int i = tid; i < 1024; i += 256) dst[i] = (xs[i] + xs[1024 + i]) + (xs[2048 + i] + xs[3072 + i]);
     }
+    if (do_bias) {
+        __syncthreads();
+        xs[tid] = bsum;
+        __syncthreads();
+        if (tid < 32) {
+            float s = 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) s += xs[k * 32 + tid];
+            a.bscratch[((size_t)blockIdx.x * (gridDim.y / a.nci) + cot) * 32 + tid] = s;
+        }
+    }
 }
 
 // Threads walk the partials in their own order (tile, tap, 32x32 element) so the reads of every
 // split are coalesced; four thread groups share the splits of an element.
 __global__ void wgrad_reduce_kernel(const float *__restrict__ scratch, float *__restrict__ dw, int splits, int nct,
-                                    int nci, int T, int Cout, int C, int CinT, int cin_offset) {
+                                    int nci, int T, int Cout, int C, int CinT, int cin_offset, int overwrite,
+                                    const float *__restrict__ bscratch, float *__restrict__ db, int nb_main) {
     __shared__ float sm[256];
     const int t = threadIdx.x, lane = t & 63, part = t >> 6;
+    if ((int)blockIdx.x >= nb_main) {  // trailing workgroups: the bias gradient's partials
+        const int nco = nct / nci;
+        const int co = ((int)blockIdx.x - nb_main) * 64 + lane;
+        float s = 0.f;
+        if (co < nco * 32)
+            for (int k = part; k < splits; k += 4) s += bscratch[(size_t)k * nco * 32 + co];
+        sm[t] = s;
+        __syncthreads();
+        if (part == 0 && co < Cout) db[co] = (sm[lane] + sm[64 + lane]) + (sm[128 + lane] + sm[192 + lane]);
+        return;
+    }
     const int64_t idx = (int64_t)blockIdx.x * 64 + lane;  // over nct * T * 1024
     const int64_t total = (int64_t)nct * T * 1024;
     float s = 0.f;
@@ -262,7 +295,10 @@ __global__ void wgrad_reduce_kernel(const float *__restrict__ scratch, float *__
         const int tap = (int)((idx >> 10) % T);
         const int tile = (int)(idx / ((int64_t)T * 1024));
         const int co = (tile / nci) * 32 + (e >> 5), ci = (tile % nci) * 32 + (e & 31);
-        if (co < Cout && ci < C) dw[((size_t)co * CinT + cin_offset + ci) * T + tap] += r;
+        if (co < Cout && ci < C) {
+            float *d = &dw[((size_t)co * CinT + cin_offset + ci) * T + tap];
+            *d = overwrite ? r : *d + r;
+        }
     }
 }
 
@@ -777,7 +813,8 @@ extern "C" int dcvc_conv_bwd_prologue(const dcvc_conv_bwd_args *a, void *stream)
 
 extern "C" int64_t dcvc_conv_wgrad_scratch_min(int32_t Cout, int32_t C, int32_t ks) {
     if (Cout <= 0 || C <= 0 || (ks != 1 && ks != 3 && ks != 7)) return DCVC_E_ARG;
-    return (int64_t)((Cout + 31) / 32) * ((C + 31) / 32) * ks * ks * 1024;
+    const int64_t nco = (Cout + 31) / 32;
+    return nco * ((C + 31) / 32) * ks * ks * 1024 + nco * 32;
 }
 
 extern "C" int dcvc_conv_wgrad(const dcvc_conv_wgrad_args *a, void *stream) {
@@ -809,6 +846,7 @@ extern "C" int dcvc_conv_wgrad(const dcvc_conv_wgrad_args *a, void *stream) {
     k.Wo = a->Wo;
     k.Cout = a->Cout;
     k.scratch = a->scratch;
+    k.bscratch = nullptr;
     k.nci = (a->C + 31) / 32;
     const int nco = (a->Cout + 31) / 32, nct = nco * k.nci;
     const int TW = a->stride == 1 ? 32 : 16;
@@ -822,6 +860,7 @@ extern "C" int dcvc_conv_wgrad(const dcvc_conv_wgrad_args *a, void *stream) {
     if (splits > 256) splits = 256;
     if (splits > ntiles) splits = ntiles;
     if (splits > a->scratch_floats / per_split) splits = a->scratch_floats / per_split;
+    if (a->db) k.bscratch = a->scratch + (size_t)splits * nct * k.T * 1024;
     hipStream_t st = (hipStream_t)stream;
     dim3 grid((unsigned)splits, (unsigned)nct, (unsigned)groups);
     if (a->ks == 3 && a->stride == 1) hipLaunchKernelGGL((wgrad_kernel<3, 1>), grid, dim3(256), 0, st, k);
@@ -831,8 +870,9 @@ extern "C" int dcvc_conv_wgrad(const dcvc_conv_wgrad_args *a, void *stream) {
     else hipLaunchKernelGGL((wgrad_kernel<7, 1>), grid, dim3(256), 0, st, k);
     if (hipGetLastError() != hipSuccess) return DCVC_E_LAUNCH;
     const int64_t nel = (int64_t)nct * k.T * 1024;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(nblk(nel, 64)), dim3(256), 0, st, a->scratch, a->dw, (int)splits, nct,
-                       k.nci, k.T, a->Cout, a->C, a->Cin_total, a->cin_offset);
+    const int nb_main = (int)nblk(nel, 64), nb_bias = a->db ? (nco * 32 + 63) / 64 : 0;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(nb_main + nb_bias), dim3(256), 0, st, a->scratch, a->dw, (int)splits, nct,
+                       k.nci, k.T, a->Cout, a->C, a->Cin_total, a->cin_offset, a->overwrite, k.bscratch, a->db, nb_main);
     RET_LAUNCH();
 }
 

@@ -76,10 +76,11 @@ class Tape:
         self.pool_left -= n4
         return chunk[off : off + n]
 
-    def pgrad(self, p: torch.Tensor):
+    def pgrad(self, p: torch.Tensor, zero=True):
+        """zero=False: the caller's kernel writes (=) every element, so no fill launch is spent."""
         g = self.pgrads.get(id(p))
         if g is None:
-            g = torch.zeros_like(p, memory_format=torch.contiguous_format)
+            g = (torch.zeros_like if zero else torch.empty_like)(p, memory_format=torch.contiguous_format)
             self.pgrads[id(p)] = g
         return g
 
@@ -163,15 +164,19 @@ class Tape:
                 dg = torch.zeros_like(gate)
                 self.vec[gate.data_ptr()] = dg
             self.channel_dot(dout, res, dg, over_batch=False, accumulate=True)
-        if self.wants(pk.bias):
-            self.channel_dot(dpre, None, self.pgrad(pk.bias), over_batch=True, accumulate=True)
         off = 0 if pk.cin_slice is None else pk.cin_slice[0]
         cin_total = pk.weight.shape[1]
+        fused_bias = self.wants(pk.bias) and self.wants(pk.weight) and id(pk.bias) not in self.pgrads
+        if self.wants(pk.bias) and not fused_bias:
+            self.channel_dot(dpre, None, self.pgrad(pk.bias), over_batch=True, accumulate=True)
         if self.wants(pk.weight):
-            dw = self.pgrad(pk.weight)
+            # a layer whose segments cover every input channel writes its whole gradient: no zero fill
+            whole = sum(s.C for s in srcs) == cin_total and id(pk.weight) not in self.pgrads
+            dw = self.pgrad(pk.weight, zero=not whole)
+            db = self.pgrad(pk.bias, zero=False) if fused_bias else None
             sc = e.fbuf("wgrad_scratch", WGRAD_SCRATCH_FLOATS, scratch=True)
             o = off
-            for s in srcs:
+            for si, s in enumerate(srcs):
                 w = lib.WgradArgs()
                 w.x, w.x_cs, w.C = s.ptr, s.cs, s.C
                 w.in_act, w.in_slope = (0, 0.0) if in_slope is None else (1, float(in_slope))
@@ -179,6 +184,9 @@ class Tape:
                 w.N, w.Hin, w.Win, w.Ho, w.Wo, w.Cout, w.ks, w.stride = N, s.H, s.W, Ho, Wo, Cout, ks, stride
                 w.dw, w.Cin_total, w.cin_offset = dw.data_ptr(), cin_total, o
                 w.scratch, w.scratch_floats = sc.data_ptr(), sc.numel()
+                w.overwrite = int(whole)
+                if db is not None and si == 0:  # the bias gradient rides on the first segment's pass over dY
+                    w.db = db.data_ptr()
                 lib.check(L.dcvc_conv_wgrad(C.byref(w), self.stream()), "conv_wgrad")
                 o += s.C
         # data gradient: the forward kernel on the flipped / transposed filter, one launch per segment
