@@ -182,48 +182,101 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradK a) {
     const bool do_bias = a.bscratch != nullptr && cit == 0 && grp == 0;
     float bsum = 0.f;
 
-    const int ntiles = a.N * a.nty * a.ntx;
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    // Software pipeline over the workgroup's tiles: the global loads of tile k+1 are in flight in
+    // registers while the MFMAs of tile k run; channel masks and the activation are applied when the
+    // registers are written to LDS, so nothing waits on the loads early.
+    constexpr int ND = (R * TW * 8 + 255) / 256, NX = (PH * PW * 8 + 255) / 256;
+    f32x4 rd[ND], rx[NX];
+    unsigned okd = 0, okx = 0;
+    const bool vd = !(a.dpre_cs & 3) && !((uintptr_t)a.dpre & 15);
+    const bool vx = !(a.x_cs & 3) && !((uintptr_t)a.x & 15);
+    auto load4 = [](const float *src, bool vec, int c, int C) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (vec) {
+            v = *(const f32x4 *)src;  // in bounds: c + 3 < round4(C) <= channel stride
+        } else {
+            v[0] = src[0];
+            if (c + 1 < C) v[1] = src[1];
+            if (c + 2 < C) v[2] = src[2];
+            if (c + 3 < C) v[3] = src[3];
+        }
+        return v;
+    };
+    auto load_tile = [&](int tile) {
         const int tx = tile % a.ntx, ty = (tile / a.ntx) % a.nty, n = tile / (a.ntx * a.nty);
-        __syncthreads();
-        // dY tile: R x TW pixels x 32 output channels
-        for (int i = tid; i < R * TW * 8; i += 256) {
+        okd = 0;
+        okx = 0;
+#pragma unroll
+        for (int u = 0; u < ND; ++u) {
+            const int i = tid + u * 256;
             const int p = i >> 3, q = i & 7;
             const int r = p / TW, xx = p - r * TW;
             const int oy = ty * R + r, ox = tx * TW + xx;
             const int c = co0 + q * 4;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (oy < a.Ho && ox < a.Wo && c < a.Cout) {
-                const float *src = a.dpre + (((size_t)n * a.Hd + (size_t)oy * a.zs) * a.Wd + (size_t)ox * a.zs) * a.dpre_cs + c;
-                v[0] = src[0];
-                if (c + 1 < a.Cout) v[1] = src[1];
-                if (c + 2 < a.Cout) v[2] = src[2];
-                if (c + 3 < a.Cout) v[3] = src[3];
+            if (i < R * TW * 8 && oy < a.Ho && ox < a.Wo && c < a.Cout) {
+                rd[u] = load4(a.dpre + (((size_t)n * a.Hd + (size_t)oy * a.zs) * a.Wd + (size_t)ox * a.zs) * a.dpre_cs + c, vd, c,
+                              a.Cout);
+                okd |= 1u << u;
             }
-            *(f32x4 *)&dys[p * 32 + q * 4] = v;
         }
-        // input patch: PH x PW pixels x 32 input channels
         const int gy0 = ty * R * S - PAD + ky0, gx0 = tx * TW * S - PAD;
-        for (int i = tid; i < PH * PW * 8; i += 256) {
+#pragma unroll
+        for (int u = 0; u < NX; ++u) {
+            const int i = tid + u * 256;
             const int p = i >> 3, q = i & 7;
             const int py = p / PW, px = p - py * PW;
             const int gy = gy0 + py, gx = gx0 + px;
             const int c = ci0 + q * 4;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (gy >= 0 && gy < a.Hin && gx >= 0 && gx < a.Win && c < a.C) {
-                const float *src = a.x + (((size_t)n * a.Hin + gy) * a.Win + gx) * a.x_cs + c;
-                v[0] = src[0];
-                if (c + 1 < a.C) v[1] = src[1];
-                if (c + 2 < a.C) v[2] = src[2];
-                if (c + 3 < a.C) v[3] = src[3];
-                if (a.in_act) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * a.in_slope;
-                }
+            if (i < PH * PW * 8 && gy >= 0 && gy < a.Hin && gx >= 0 && gx < a.Win && c < a.C) {
+                rx[u] = load4(a.x + (((size_t)n * a.Hin + gy) * a.Win + gx) * a.x_cs + c, vx, c, a.C);
+                okx |= 1u << u;
             }
-            *(f32x4 *)&xs[p * 32 + q * 4] = v;
         }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int u = 0; u < ND; ++u) {
+            const int i = tid + u * 256;
+            if (i < R * TW * 8) {
+                const int c = co0 + (i & 7) * 4;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if ((okd >> u) & 1u) {
+                    v = rd[u];
+                    if (c + 1 >= a.Cout) v[1] = 0.f;
+                    if (c + 2 >= a.Cout) v[2] = 0.f;
+                    if (c + 3 >= a.Cout) v[3] = 0.f;
+                }
+                *(f32x4 *)&dys[(i >> 3) * 32 + (i & 7) * 4] = v;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < NX; ++u) {
+            const int i = tid + u * 256;
+            if (i < PH * PW * 8) {
+                const int c = ci0 + (i & 7) * 4;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if ((okx >> u) & 1u) {
+                    v = rx[u];
+                    if (c + 1 >= a.C) v[1] = 0.f;
+                    if (c + 2 >= a.C) v[2] = 0.f;
+                    if (c + 3 >= a.C) v[3] = 0.f;
+                    if (a.in_act) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * a.in_slope;
+                    }
+                }
+                *(f32x4 *)&xs[(i >> 3) * 32 + (i & 7) * 4] = v;
+            }
+        }
+    };
+
+    const int ntiles = a.N * a.nty * a.ntx;
+    if ((int)blockIdx.x < ntiles) load_tile(blockIdx.x);
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        __syncthreads();  // the previous tile's LDS reads are done
+        store_tile();
         __syncthreads();
+        if (tile + (int)gridDim.x < ntiles) load_tile(tile + gridDim.x);
         if (do_bias) {
 #pragma unroll 4
             for (int p = tid >> 5; p < R * TW; p += 8) bsum += dys[p * 32 + (tid & 31)];
@@ -855,10 +908,13 @@ extern "C" int dcvc_conv_wgrad(const dcvc_conv_wgrad_args *a, void *stream) {
     k.T = a->ks * a->ks;
     const int groups = a->ks == 7 ? 7 : 1;
     const int64_t ntiles = (int64_t)a->N * k.ntx * k.nty;
-    int64_t splits = 2048 / ((int64_t)nct * groups);
-    if (splits < 1) splits = 1;
+    // pixel splits: enough workgroups to fill the chip (~512), more only while every workgroup
+    // still keeps >= 8 tiles to amortise its cross-wave reduction and its partial in scratch
+    int64_t splits = (512 + (int64_t)nct * groups - 1) / ((int64_t)nct * groups);
+    if (ntiles / 8 > splits) splits = ntiles / 8;
     if (splits > 256) splits = 256;
     if (splits > ntiles) splits = ntiles;
+    if (splits < 1) splits = 1;
     if (splits > a->scratch_floats / per_split) splits = a->scratch_floats / per_split;
     if (a->db) k.bscratch = a->scratch + (size_t)splits * nct * k.T * 1024;
     hipStream_t st = (hipStream_t)stream;
