@@ -350,3 +350,25 @@ def test_escape_coded_symbols_round_trip(nets):
     dd = d.decompress(dpb, c["bit_stream"], h, w, 0.01, 0.01)
     for k in enc:
         assert torch.equal(dd["dpb"][k], enc[k]), k
+
+
+def test_graph_replay_encodes_identically(nets):
+    """GopEncoder(graphs=True): P pictures replayed as captured hipGraphs give the same payload bytes
+    and the same DPB as eager launches, across GOP boundaries (first-P graphs, both DPB buffer sets)."""
+    from vcm_ts_amd.pipeline import GopEncoder
+
+    d, i = nets
+    dev = torch.device("cuda:0")
+    fr = frames(33, 11, 128, 192)
+    seq = [torch.from_numpy(fr[t : t + 1]).to(dev) for t in range(11)]
+    eager, bits_e, dpb_e = GopEncoder(i, d, gop_size=4).encode_gop(seq, 1.0, 1.0, 1.0)
+    ref = dpb_e["ref_frame"].clone()
+    enc = GopEncoder(i, d, gop_size=4, graphs=True)
+    for rep in range(2):  # second pass: pure replays
+        coded, bits_g, dpb_g = enc.encode_gop(seq, 1.0, 1.0, 1.0)
+        assert bits_g == bits_e and [c[2] for c in coded] == [c[2] for c in eager], rep
+        assert torch.equal(dpb_g["ref_frame"], ref), rep
+    assert 2 <= len(d._graphs) <= 8
+    with pytest.raises(TypeError):
+        d.compress(seq[1], {"ref_frame": seq[0], "ref_feature": None, "ref_y": None, "ref_mv_y": None},
+                   torch.tensor(1.0), 1.0, graph=True)

@@ -30,6 +30,7 @@ import torch
 from torch import nn
 
 from . import entropy as E
+from . import lib
 from . import stream as S
 from .engine import Engine, View
 from .nets import Net
@@ -107,6 +108,7 @@ class CodecBase(nn.Module):
         self._flip = 0
         self._chan_cache, self._stage_bufs, self._stage_flip, self._stage_owner = {}, {}, 0, {}
         self._dcoder, self._dc_active, self._dc_stream, self._dc_done = None, False, None, None
+        self._graphs = {}
 
     # -- plumbing ------------------------------------------------------------------------
     def P(self, name):
@@ -236,6 +238,18 @@ class CodecBase(nn.Module):
         self._stage_owner[slot] = pending
         return pending
 
+    @staticmethod
+    def _stage_layout(planes):
+        layout, off = [], 0
+        for table, sym, idx, chan in planes:
+            n = sym.numel()
+            s_off, off = off, off + n
+            i_off = None
+            if idx is not None:
+                i_off, off = off, off + n
+            layout.append((table, s_off, i_off, n, chan))
+        return layout, off
+
     # -- opt-in device entropy coder (include/dcvc_hip_rans.h; NOT the reference's wire format) ---
     def device_coder(self) -> "E.DeviceCoder":
         if self._tables is None:
@@ -349,12 +363,6 @@ class CodecBase(nn.Module):
         sym = self._decode_scale(idx)
         e.dual_prior("dec_apply", 1, spatial=spatial, sym=sym, out=out, q_basic=q_basic, q_scale=q_scale, **common)
         return out
-
-
-def lib_check(code, what):
-    from . import lib
-
-    lib.check(code, what)
 
 
 class _FrameFn(torch.autograd.Function):
@@ -566,7 +574,7 @@ class DMC(CodecBase):
                 per = lat.HW * lat.C
                 noise = self._noise(nkey, N, lat.H, lat.W, lat.C)
                 y_bit = torch.empty_like(noise).view(-1)
-                lib_check(L.dcvc_add_planes(r["y_res"].data_ptr(), lat.C, noise.data_ptr(), lat.C, y_bit.data_ptr(), lat.C,
+                lib.check(L.dcvc_add_planes(r["y_res"].data_ptr(), lat.C, noise.data_ptr(), lat.C, y_bit.data_ptr(), lat.C,
                                             N * lat.HW, lat.C, e.stream()), "add_planes")
                 sums[name] = e.scale_bits(y_bit, r["scales_hat"], N, per)
                 tape.ops.append(("scale_bits", name, y_bit, r["scales_hat"], r["y_res"], N, per))
@@ -574,7 +582,7 @@ class DMC(CodecBase):
                                        ("bits_mv_z", o["mv_z"], "bit_estimator_z_mv", "mv_z")):
                 noise = self._noise(nkey, N, z.H, z.W, z.C)
                 z_bit = View(torch.empty_like(noise), z.C)
-                lib_check(L.dcvc_add_planes(z.ptr, z.cs, noise.data_ptr(), z.C, z_bit.ptr, z_bit.cs, N * z.HW, z.C,
+                lib.check(L.dcvc_add_planes(z.ptr, z.cs, noise.data_ptr(), z.C, z_bit.ptr, z_bit.cs, N * z.HW, z.C,
                                             e.stream()), "add_planes")
                 blk = self._zblock(est)
                 sums[name] = e.factorized_bits(z_bit, blk)
@@ -638,12 +646,79 @@ class DMC(CodecBase):
     def forward(self, x, dpb, mv_y_q_scale=None, y_q_scale=None):
         return self.forward_one_frame(x, dpb, mv_y_q_scale=mv_y_q_scale, y_q_scale=y_q_scale)
 
+    def _compress_graph(self, x, dpb, mv_y_q_scale, y_q_scale):
+        """compress() as a hipGraph replay.  A P picture is ~235 launches; at small picture sizes the
+        host cannot enqueue them as fast as the GPU runs them (256x256: 2.8 ms of enqueue for ~1.5 ms
+        of kernels), so the launch sequence is captured once per (picture size, q-scales, DPB buffer
+        set) and replayed.  Everything a replay touches is static: the picture is copied into a fixed
+        input buffer first, the DPB alternates between the engine's two output sets (one graph each),
+        the symbol planes land in a pinned host buffer owned by the graph."""
+        if not all(isinstance(q, (int, float)) for q in (mv_y_q_scale, y_q_scale)):
+            raise TypeError("graph replay needs plain float q-scales (they are baked into the captured launches)")
+        if x.shape[0] != 1:
+            raise NotImplementedError("graph replay codes one picture per call")
+        ptrs = tuple(None if dpb.get(k) is None else (dpb[k].data_ptr(), tuple(dpb[k].shape), tuple(dpb[k].stride()))
+                     for k in ("ref_frame", "ref_feature", "ref_y", "ref_mv_y"))
+        key = (tuple(x.shape), ptrs, self._flip, float(mv_y_q_scale), float(y_q_scale))
+        g = self._graphs.get(key)
+        if g is None:
+            if len(self._graphs) >= 8:
+                self._graphs.pop(next(iter(self._graphs)))
+            xs = torch.empty_like(x, memory_format=torch.contiguous_format)
+            xs.copy_(x)
+            flip0 = self._flip
+            # eager warm-up with the same state: packs weights, allocates every buffer (nothing may be
+            # allocated while capturing); its results are overwritten by the identical captured run
+            o = self._run(xs, dpb, mv_y_q_scale, y_q_scale, "compress")
+            zm, zz = o["mv_z_hat"], o["z_hat"]
+            planes = lambda o: [("bit_estimator_z_mv", o["sym_mv_z"], None, (1, 64, zm.H, zm.W)),
+                                ("scale", o["r_mv"]["sym"][0], o["r_mv"]["idx"][0], None),
+                                ("scale", o["r_mv"]["sym"][1], o["r_mv"]["idx"][1], None),
+                                ("bit_estimator_z", o["sym_z"], None, (1, 64, zz.H, zz.W)),
+                                ("scale", o["r_y"]["sym"][0], o["r_y"]["idx"][0], None),
+                                ("scale", o["r_y"]["sym"][1], o["r_y"]["idx"][1], None)]
+            layout, total = self._stage_layout(planes(o))
+            host = torch.empty(total, dtype=torch.int32, pin_memory=True)
+            torch.cuda.synchronize(self.device)
+            self._flip = flip0
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                o = self._run(xs, dpb, mv_y_q_scale, y_q_scale, "compress")
+                for (table, s_off, i_off, n, chan), (_, sym, idx, _) in zip(layout, planes(o)):
+                    host[s_off : s_off + n].copy_(sym, non_blocking=True)
+                    if idx is not None:
+                        host[i_off : i_off + n].copy_(idx, non_blocking=True)
+            g = dict(graph=graph, xs=xs, host=host, layout=layout, out=self._dpb_out(o), views=o, flip_after=self._flip,
+                     pending=None)
+            self._graphs[key] = g
+        prev = g["pending"]
+        if prev is not None and prev._streams is None:
+            raise RuntimeError("this graph's previous picture has not been retired: call pending.finish() first")
+        g["xs"].copy_(x)
+        g["graph"].replay()
+        self._flip = g["flip_after"]
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device))
+        g["pending"] = PendingStream(self, g["host"], ev, g["layout"], 1)
+        return g
+
     @torch.no_grad()
-    def compress(self, x, dpb, mv_y_q_scale, y_q_scale, defer=False, coder="host"):
+    def compress(self, x, dpb, mv_y_q_scale, y_q_scale, defer=False, coder="host", graph=False):
         """defer=True returns {"dpb", "pending"}: call pending.finish() later for the bytes.
-        coder="device": opt-in lane-interleaved GPU coder (include/dcvc_hip_rans.h, its own format)."""
+        coder="device": opt-in lane-interleaved GPU coder (include/dcvc_hip_rans.h, its own format).
+        graph=True: replay the picture's launches as a captured hipGraph (host coder, batch 1, float
+        q-scales): pays when the picture is small enough for the host enqueue to be the bottleneck."""
         if self.entropy_coder is None:
             raise RuntimeError("call update() before compress()/decompress()")
+        if graph:
+            if coder != "host":
+                raise NotImplementedError("graph replay is wired to the host coder")
+            g = self._compress_graph(x, dpb, mv_y_q_scale, y_q_scale)
+            d = g["out"]
+            if defer:
+                return {"dbp": d, "dpb": d, "pending": g["pending"], "_views": g["views"]}
+            streams = g["pending"].finish_all()
+            return {"dbp": d, "dpb": d, "bit_stream": streams[0], "bit_streams": streams, "_views": g["views"]}
         o = self._run(x, dpb, mv_y_q_scale, y_q_scale, "compress")
         N = o["N"]  # N > 1: a batch of rate points, one independent stream per element ("bit_streams")
         zm, zz = o["mv_z_hat"], o["z_hat"]

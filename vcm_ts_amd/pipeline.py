@@ -57,11 +57,13 @@ def timed_region(fn, device=None):
 
 
 class GopEncoder:
-    def __init__(self, i_frame_net, p_frame_net, gop_size=32, coder="host"):
+    def __init__(self, i_frame_net, p_frame_net, gop_size=32, coder="host", graphs=False):
         """coder="device": payloads in the opt-in GPU format of include/dcvc_hip_rans.h (symbol planes
-        never leave the device; decode_gop recognises them by their magic)."""
-        assert coder in ("host", "device")
-        self.i_net, self.p_net, self.gop, self.coder = i_frame_net, p_frame_net, int(gop_size), coder
+        never leave the device; decode_gop recognises them by their magic).  graphs=True: P pictures
+        are replayed as captured hipGraphs (same results; for picture sizes where ~235 launches per
+        picture make the host the bottleneck)."""
+        assert coder in ("host", "device") and not (graphs and coder != "host")
+        self.i_net, self.p_net, self.gop, self.coder, self.graphs = i_frame_net, p_frame_net, int(gop_size), coder, graphs
         self.i_net.update()
         self.p_net.update()
 
@@ -93,7 +95,7 @@ class GopEncoder:
                 dpb = {"ref_frame": r["x_hat"], "ref_feature": None, "ref_y": None, "ref_mv_y": None}
                 item = ("I", (qi_idx,), r["pending"], t)
             else:
-                r = self.p_net.compress(x, dpb, q_mv_y, q_y, defer=True, coder=self.coder)
+                r = self.p_net.compress(x, dpb, q_mv_y, q_y, defer=True, coder=self.coder, graph=self.graphs)
                 dpb = r["dpb"]
                 item = ("P", (qmv_idx, qy_idx), r["pending"], t)
             if on_recon is not None:  # reconstruction == what the decoder will produce (clamped)
