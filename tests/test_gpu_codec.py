@@ -372,3 +372,28 @@ def test_graph_replay_encodes_identically(nets):
     with pytest.raises(TypeError):
         d.compress(seq[1], {"ref_frame": seq[0], "ref_feature": None, "ref_y": None, "ref_mv_y": None},
                    torch.tensor(1.0), 1.0, graph=True)
+
+
+def test_concurrent_gop_streams_encode_identically():
+    """ConcurrentGopEncoder: two GOPs in flight on two HIP streams (own codec instances each, one host
+    thread) produce exactly the payloads and reconstructions of coding them one after the other."""
+    from vcm_ts_amd.dmc import DMC
+    from vcm_ts_amd.intra import IntraNoAR
+    from vcm_ts_amd.pipeline import ConcurrentGopEncoder, GopEncoder
+
+    dev = torch.device("cuda:0")
+    make = lambda: (IntraNoAR().to(dev).eval(), DMC().to(dev).eval())
+    seqs = []
+    for k in range(2):
+        fr = frames(60 + k, 5, 128, 192)
+        seqs.append([torch.from_numpy(fr[t : t + 1]).to(dev) for t in range(5)])
+    cenc = ConcurrentGopEncoder(make, gop_size=5, streams=2)
+    res = cenc.encode_gops(seqs, 1.0, 1.0, 1.0)
+    one = GopEncoder(*make(), gop_size=5)
+    for k in range(2):
+        coded, bits, dpb = one.encode_gop(seqs[k], 1.0, 1.0, 1.0)
+        assert [c[2] for c in coded] == [c[2] for c in res[k][0]] and bits == res[k][1], k
+        assert torch.equal(dpb["ref_frame"], res[k][2]["ref_frame"]), k
+    # a single sequence works too (fewer sequences than streams)
+    again = cenc.encode_gops(seqs[:1], 1.0, 1.0, 1.0)
+    assert [c[2] for c in again[0][0]] == [c[2] for c in res[0][0]]
