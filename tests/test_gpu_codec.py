@@ -397,3 +397,9 @@ def test_concurrent_gop_streams_encode_identically():
     # a single sequence works too (fewer sequences than streams)
     again = cenc.encode_gops(seqs[:1], 1.0, 1.0, 1.0)
     assert [c[2] for c in again[0][0]] == [c[2] for c in res[0][0]]
+    # concurrent decode (one thread + stream per GOP) == sequential decode == the encoders' reconstructions
+    recs = cenc.decode_gops([r[0] for r in res], 128, 192)
+    for k in range(2):
+        want = one.decode_gop(res[k][0], 128, 192)
+        assert len(recs[k]) == 5 and all(torch.equal(a, b) for a, b in zip(recs[k], want)), k
+        assert torch.equal(recs[k][-1], res[k][2]["ref_frame"]), k

@@ -176,3 +176,33 @@ class ConcurrentGopEncoder:
         for s in self.streams[: len(sequences)]:
             cur.wait_stream(s)
         return [(r["coded"], r["bits"], r["dpb"]) for r in results]
+
+    def decode_gops(self, coded_gops, height, width):
+        """Decode up to `streams` GOPs at once: one host thread and one HIP stream per GOP (the
+        reference bitstream forces six host round trips per P picture; while one GOP's thread waits
+        for its symbols the other GOP's kernels run).  Returns one list of reconstructions per GOP."""
+        import threading
+
+        assert len(coded_gops) <= len(self.encoders)
+        cur = torch.cuda.current_stream(self.device)
+        out, errs = [None] * len(coded_gops), []
+
+        def work(k):
+            try:
+                with torch.cuda.stream(self.streams[k]):
+                    out[k] = self.encoders[k].decode_gop(coded_gops[k], height, width)
+            except BaseException as ex:  # re-raised in the caller's thread
+                errs.append(ex)
+
+        for k in range(len(coded_gops)):
+            self.streams[k].wait_stream(cur)
+        threads = [threading.Thread(target=work, args=(k,)) for k in range(len(coded_gops))]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        if errs:
+            raise errs[0]
+        for s in self.streams[: len(coded_gops)]:
+            cur.wait_stream(s)
+        return out
