@@ -93,6 +93,12 @@ class Tape:
     def scratch(self, n):
         return self.e.fbuf("grad_scratch", n, scratch=True)
 
+    def side_stream(self):
+        if getattr(self.e, "_wgrad_stream", None) is None:
+            self.e._wgrad_stream = torch.cuda.Stream(self.e.device)
+        self.used_side = True
+        return self.e._wgrad_stream
+
     # ------------------------------------------------------------------ kernels
     def channel_dot(self, a: View, b, out: torch.Tensor, over_batch, accumulate):
         sc = self.scratch(a.N * 256 * _r4(max(a.C, 4)))
@@ -114,6 +120,8 @@ class Tape:
                 getattr(self, "_b_" + op[0])(*op[1:])
             for qk, q in self.q.items():
                 self._q_finish(q)
+            if getattr(self, "used_side", False):  # parameter gradients are complete for the caller's stream
+                torch.cuda.current_stream(e.device).wait_stream(e._wgrad_stream)
         finally:
             e.tape = saved
 
@@ -175,6 +183,18 @@ class Tape:
             dw = self.pgrad(pk.weight, zero=not whole)
             db = self.pgrad(pk.bias, zero=False) if fused_bias else None
             sc = e.fbuf("wgrad_scratch", WGRAD_SCRATCH_FLOATS, scratch=True)
+            # Weight gradients are needed only at the end of the pass and depend on nothing but dpre
+            # and the stored activations: they run on a second stream beside the data-gradient chain
+            # (the only chain the next layer waits for), so the two kinds of launches fill each
+            # other's idle CUs.
+            main = torch.cuda.current_stream(e.device)
+            side = self.side_stream()
+            ready = torch.cuda.Event()
+            ready.record(main)
+            side.wait_event(ready)
+            if need_pro:
+                dpre.base.record_stream(side)  # a temporary: keep the allocator from recycling it early
+            wstream = C.c_void_p(side.cuda_stream)
             o = off
             for si, s in enumerate(srcs):
                 w = lib.WgradArgs()
@@ -187,7 +207,7 @@ class Tape:
                 w.overwrite = int(whole)
                 if db is not None and si == 0:  # the bias gradient rides on the first segment's pass over dY
                     w.db = db.data_ptr()
-                lib.check(L.dcvc_conv_wgrad(C.byref(w), self.stream()), "conv_wgrad")
+                lib.check(L.dcvc_conv_wgrad(C.byref(w), wstream), "conv_wgrad")
                 o += s.C
         # data gradient: the forward kernel on the flipped / transposed filter, one launch per segment
         o = off
