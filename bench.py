@@ -124,19 +124,6 @@ def train_workload(args, dev, rank, world):
     prof = eng.collect_profile()
     eng.profile = None
     dom = prof.get("conv3x3s1", {"flops": 0.0, "ms": 1.0, "launches": 0})
-    # the same kernel while K GOP streams are in flight (what a rocprof trace of this command shows):
-    # launches of the streams overlap, so each takes longer although together they finish sooner
-    in_flight_ms = None
-    if K > 1:
-        engines = [e_.p_net.engine() for e_ in cenc.encoders]
-        for g in engines:
-            g.profile = {}
-        cenc.encode_gops([sq[:4] for sq in seqs], q_i, q_mv, q_y)
-        both = [g.collect_profile().get("conv3x3s1", {"ms": 0.0, "launches": 0}) for g in engines]
-        for g in engines:
-            g.profile = None
-        n_l = sum(b["launches"] for b in both)
-        in_flight_ms = round(sum(b["ms"] for b in both) / max(n_l, 1), 4)
     peak = PEAK_F32_MFMA_TFLOPS if prec == "fp32" else PEAK_F16_MFMA_TFLOPS / 3.0
     achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
     out = {"metric": "trainer step pictures/sec (batch 4 x 256x256 per GPU, bpp+MSE, AdamW)", "value": round(world * batch * args.steps / dt, 2),
