@@ -109,6 +109,7 @@ class CodecBase(nn.Module):
         self._chan_cache, self._stage_bufs, self._stage_flip, self._stage_owner = {}, {}, 0, {}
         self._dcoder, self._dc_active, self._dc_stream, self._dc_done = None, False, None, None
         self._graphs = {}
+        self._fork_stream = None
 
     # -- plumbing ------------------------------------------------------------------------
     def P(self, name):
@@ -282,6 +283,25 @@ class CodecBase(nn.Module):
             pending = dc.end()
         self._dc_done = pending.event
         return pending
+
+    fork_features = True  # run the DPB-only feature pyramid on a side stream beside the motion path
+
+    def _fork_pyramid(self, net, dv, tape):
+        """Start Net.feature_pyramid on a side stream (inference only: a recorded training forward and
+        a graph capture stay single-stream).  Returns (pyramid or None, join event or None)."""
+        if not self.fork_features or tape is not None or torch.cuda.is_current_stream_capturing():
+            return None, None
+        main = torch.cuda.current_stream(self.device)
+        if self._fork_stream is None:
+            self._fork_stream = torch.cuda.Stream(self.device)
+        start = torch.cuda.Event()
+        start.record(main)       # everything of the previous picture (readers of these buffers, the DPB) is before this
+        self._fork_stream.wait_event(start)
+        with torch.cuda.stream(self._fork_stream):
+            pyr = net.feature_pyramid(dv["ref_frame"], dv["ref_feature"])
+            done = torch.cuda.Event()
+            done.record(self._fork_stream)
+        return pyr, done
 
     def _wait_coder(self):
         if self._dc_done is not None:
@@ -490,6 +510,7 @@ class DMC(CodecBase):
         dv = self._views_of_dpb(dpb)
         k = self._out_set(*dv.values()) if tape is None else 0
         # current frame lives in channels 0-2 of SpyNet's finest 8-channel input buffer
+        pyr, pyr_done = self._fork_pyramid(net, dv, tape)
         spy0 = e.buf("dmc/spy.in0", N, H, W, 8)
         x3 = e.from_nchw(x, spy0.slice(0, 3))
         if tape is not None:  # pictures and detached DPB entries carry no gradient
@@ -512,8 +533,10 @@ class DMC(CodecBase):
         mv_hat = net.decoder_stack("mv_decoder", mv_y_hat)
         enc_cat2 = net.buf("enc_cat2", N=N, H=H // 2, W=W // 2, C=128)
         enc_cat3 = net.buf("enc_cat3", N=N, H=H // 4, W=W // 4, C=128)
+        if pyr_done is not None:
+            torch.cuda.current_stream(self.device).wait_event(pyr_done)
         c1, c2, c3, warp_frame = net.motion_compensation(dv["ref_frame"], dv["ref_feature"], mv_hat, enc_cat2, enc_cat3,
-                                                         want_warp_frame=(mode != "compress"))
+                                                         want_warp_frame=(mode != "compress"), pyramid=pyr)
         y_raw = net.contextual_encoder(x3, c1, enc_cat2, enc_cat3)
         y = e.scale_channels(y_raw, net.buf("y", like=y_raw, C=96), self.P("y_q_basic").reshape(-1), q_y, qkey="y")
         n_ = "contextual_hyper_prior_encoder"
@@ -766,6 +789,7 @@ class DMC(CodecBase):
             self.device_coder().set_stream(string)
         else:
             self.entropy_coder.set_stream(string)
+        pyr, pyr_done = self._fork_pyramid(net, dv, None)
         zh, zw = S.get_downsampled_shape(height, width, 64)
         H, W = zh * 64, zw * 64
         sym = self._decode_factorized("bit_estimator_z_mv", N, 64, zh, zw)
@@ -774,7 +798,9 @@ class DMC(CodecBase):
         mv_hat = net.decoder_stack("mv_decoder", mv_y_hat)
         enc_cat2 = net.buf("enc_cat2", N=N, H=H // 2, W=W // 2, C=128)
         enc_cat3 = net.buf("enc_cat3", N=N, H=H // 4, W=W // 4, C=128)
-        c1, c2, c3, _ = net.motion_compensation(dv["ref_frame"], dv["ref_feature"], mv_hat, enc_cat2, enc_cat3, False)
+        if pyr_done is not None:
+            torch.cuda.current_stream(self.device).wait_event(pyr_done)
+        c1, c2, c3, _ = net.motion_compensation(dv["ref_frame"], dv["ref_feature"], mv_hat, enc_cat2, enc_cat3, False, pyramid=pyr)
         sym = self._decode_factorized("bit_estimator_z", N, 64, zh, zw)
         z_hat = e.symbols_to_nhwc(sym, net.buf("z_hat", N=N, H=zh, W=zw, C=64))
         fusion = self._y_prior(net, dv, c3, z_hat)

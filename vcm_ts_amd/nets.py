@@ -151,8 +151,21 @@ class Net:
         return flow
 
     # ------------------------------------------------------------------ P-frame pieces
+    def feature_pyramid(self, ref_frame: View, ref_feature):
+        """feature_adaptor_I/P + FeatureExtractor (video_model.py:17-38,226-232): depends only on the
+        DPB, not on the motion of the current picture, so the codec may run it on a side stream
+        while SpyNet and the motion-vector codec run (DMC._run)."""
+        if ref_feature is None:
+            f = self.conv("feature_adaptor_I", ref_frame)
+        else:
+            f = self.conv("feature_adaptor_P", ref_feature)
+        l1 = self.res_block("feature_extractor.res_block1", self.conv("feature_extractor.conv1", f))
+        l2 = self.res_block("feature_extractor.res_block2", self.conv("feature_extractor.conv2", l1, stride=2))
+        l3 = self.res_block("feature_extractor.res_block3", self.conv("feature_extractor.conv3", l2, stride=2))
+        return l1, l2, l3
+
     def motion_compensation(self, ref_frame: View, ref_feature, mv: View, enc_cat2: View, enc_cat3: View,
-                            want_warp_frame: bool):
+                            want_warp_frame: bool, pyramid=None):
         """video_model.py:226-246 + MultiScaleContextFusion :40-68.  context2/context3 are written
         straight into the second halves of the contextual encoder's concat buffers."""
         N, H, W = mv.N, mv.H, mv.W
@@ -161,13 +174,7 @@ class Net:
             warp_frame = self.e.warp(ref_frame, mv, self.buf("warp_frame", like=mv, C=3))
         mv2 = self.e.down2(mv, self.buf("mv2", N=N, H=H // 2, W=W // 2, C=2), scale=0.5)
         mv3 = self.e.down2(mv2, self.buf("mv3", N=N, H=H // 4, W=W // 4, C=2), scale=0.5)
-        if ref_feature is None:
-            f = self.conv("feature_adaptor_I", ref_frame)
-        else:
-            f = self.conv("feature_adaptor_P", ref_feature)
-        l1 = self.res_block("feature_extractor.res_block1", self.conv("feature_extractor.conv1", f))
-        l2 = self.res_block("feature_extractor.res_block2", self.conv("feature_extractor.conv2", l1, stride=2))
-        l3 = self.res_block("feature_extractor.res_block3", self.conv("feature_extractor.conv3", l2, stride=2))
+        l1, l2, l3 = pyramid if pyramid is not None else self.feature_pyramid(ref_frame, ref_feature)
         cat1 = self.buf("fusion_cat1", like=l1, C=128)  # [context2_up | warped context1]
         c1w = self.e.warp(l1, mv, cat1.slice(64, 64))
         c3w = self.e.warp(l3, mv3, self.buf("ctx3_warp", like=l3, C=64))
