@@ -145,8 +145,9 @@ class ConcurrentGopEncoder:
     picture at a time.  GOPs are independent, so this is GOP sharding applied inside a
     GPU: while one GOP runs its 1/16- and 1/64-resolution stages (tens of small kernels that leave
     most of the 256 CUs idle) the other GOP's full-resolution convolutions fill the chip.  Payloads
-    are byte-identical to sequential encoding; two streams measured +12 % frames/s at 1080p, a third
-    adds nothing."""
+    are byte-identical to sequential encoding; two streams measured +13 % frames/s at 1080p, a third
+    adds nothing.  Every stream holds a full workspace (about 33 GB at 1088x1920, 130 GB at
+    2176x3840): use one stream for 4K pictures."""
 
     def __init__(self, make_nets, gop_size=32, streams=2, coder="host"):
         """make_nets() -> (i_frame_net, p_frame_net) on the target device, called once per stream."""
