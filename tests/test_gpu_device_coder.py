@@ -141,3 +141,26 @@ def test_codecs_round_trip_through_device_coder(precision):
     with pytest.raises(NotImplementedError):
         d.compress(torch.cat([seq[1], seq[2]]), {"ref_frame": torch.cat([seq[0], seq[0]]), "ref_feature": None, "ref_y": None,
                                                  "ref_mv_y": None}, 1.0, 1.0, coder="device")
+
+
+def test_device_coder_with_concurrent_gop_streams():
+    """Both opt-ins together: two GOPs in flight, each coding its planes on its own device coder and
+    side stream; payloads decode (concurrently, too) to the reconstructions of the host-coded path."""
+    from vcm_ts_amd.dmc import DMC
+    from vcm_ts_amd.intra import IntraNoAR
+    from vcm_ts_amd.pipeline import ConcurrentGopEncoder, GopEncoder
+
+    make = lambda: (IntraNoAR().to(DEV).eval(), DMC().to(DEV).eval())
+    seqs = []
+    for k in range(2):
+        fr = frames(80 + k, 4, 128, 192)
+        seqs.append([torch.from_numpy(fr[t : t + 1]).to(DEV) for t in range(4)])
+    cenc = ConcurrentGopEncoder(make, gop_size=4, streams=2, coder="device")
+    res = cenc.encode_gops(seqs, 1.0, 1.0, 1.0)
+    enc_ref = [r[2]["ref_frame"].clone() for r in res]   # DPB views are recycled by the decode below
+    recs = cenc.decode_gops([r[0] for r in res], 128, 192)
+    host = GopEncoder(*make(), gop_size=4)
+    for k in range(2):
+        coded, _, dpb = host.encode_gop(seqs[k], 1.0, 1.0, 1.0)
+        assert all(c[2][:4] == E.DRANS_MAGIC for c in res[k][0])
+        assert torch.equal(enc_ref[k], dpb["ref_frame"]) and torch.equal(recs[k][-1], dpb["ref_frame"]), k
