@@ -10,6 +10,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <mutex>
+
 #include "dcvc_hip_rans.h"
 
 namespace {
@@ -360,10 +362,20 @@ inline int per_lane_cap(int64_t n, int lanes) { return (int)(((n + lanes - 1) / 
 constexpr int kMaxTableEntries = 32 * 1024;  // 64 KB of LDS for the 16-bit table
 constexpr int kMaxRows = 256;                // 64 KB for the decoder's bucket table
 
+// The dynamic-LDS ceiling of a kernel is a process-wide property of the function: raise it once to
+// the most this file ever asks for (callers may be on several host threads with different tables,
+// so setting it per launch to the launch's own size would race).
+constexpr size_t kLdsCeiling = 64 * 1024 + 2 * 1024 + 64 * 1024;  // table + sizes/offsets + bucket table
+
 template <typename K>
 int set_lds(K kernel, size_t bytes) {
-    return hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess
-               ? DCVC_OK : DCVC_E_LAUNCH;
+    static std::once_flag once;
+    static int status = DCVC_OK;
+    std::call_once(once, [&] {
+        status = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsCeiling) == hipSuccess
+                     ? DCVC_OK : DCVC_E_LAUNCH;
+    });
+    return bytes <= kLdsCeiling ? status : DCVC_E_ARG;
 }
 
 inline size_t table_lds(int n_cdfs, int stride) { return (((size_t)n_cdfs * stride + 7) & ~(size_t)7) * 2 + (size_t)n_cdfs * 8; }
