@@ -116,6 +116,7 @@ def train_workload(args, dev, rank, world):
             dpb = r["dpb"]
         return float(r["loss_to_opt"].detach())
 
+    run(0, 1)  # one-off initialisation (not a step): weight packing, buffers, optimiser state
     run(0, args.warmup)
     dt, loss = timed_region(lambda: run(args.warmup, args.steps), dev)
     eng = model.dmc.engine()
