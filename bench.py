@@ -107,6 +107,7 @@ def train_workload(args, dev, rank, world):
     clip = torch.rand(batch, args.warmup + args.steps + 1, 3, size, size, generator=g).to(dev)
 
     def run(t0, n):
+        r = None
         dpb = {"ref_frame": clip[:, t0], "ref_feature": None, "ref_y": None, "ref_mv_y": None}
         for t in range(t0 + 1, t0 + 1 + n):
             opt.zero_grad()
@@ -114,7 +115,7 @@ def train_workload(args, dev, rank, world):
             r["loss_to_opt"].backward()
             opt.step()
             dpb = r["dpb"]
-        return float(r["loss_to_opt"].detach())
+        return float(r["loss_to_opt"].detach()) if r is not None else float("nan")
 
     run(0, 1)  # one-off initialisation (not a step): weight packing, buffers, optimiser state
     run(0, args.warmup)
