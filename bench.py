@@ -160,6 +160,19 @@ def train_workload(args, dev, rank, world):
     return out
 
 
+def self_launch(n):
+    import socket
+    import subprocess
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -182,9 +195,17 @@ def main():
                          "step of trainer.py / trainer_multi.py per bench step (batch 4 of 256x256 per GPU, DDP over RCCL)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` by itself: start one rank per GPU (env:// rendezvous on 127.0.0.1, as
+        # trainer_multi.py:16-39 does with mp.spawn) as a CHILD torch.distributed.run -- this process has not
+        # touched the GPU yet and never will -- and hand back its exit code.  Rank 0 prints the JSON line.
+        raise SystemExit(self_launch(args.gpus))
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch one rank per GPU "
+                         "(python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...) or let bench.py do it")
     if world > 1:
         import torch.distributed as dist
 

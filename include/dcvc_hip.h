@@ -169,9 +169,13 @@ typedef struct {
     const float *q_scale;  /* (N) */
     int32_t N, H, W, C;
     int32_t step;          /* 0 or 1 */
-    float log_scale_min;   /* ln(0.01) laplace / ln(0.11) gaussian */
-    float log_scale_step;  /* (ln 64 - log_scale_min) / 255 */
+    const float *idx_edges; /* device, 256 floats: edge[k-1] = smallest fp32 scale whose build_indexes value
+                               (entropy_models.py:264-268, torch-CPU fp32) is >= k, for k = 1..255; edge[255] =
+                               +inf.  index(s) = number of edges <= s.  Needed whenever idx is written. */
 } dcvc_dual_prior_args;
+
+/* GaussianEncoder.build_indexes (entropy_models.py:264-268) on a flat array, bit-exact through idx_edges. */
+int dcvc_scale_indexes(const float *scales, int32_t *idx, int64_t n, const float *idx_edges, void *stream);
 
 int dcvc_dual_prior_enc(const dcvc_dual_prior_args *a, void *stream);
 /* decoder step: idx only (sym == NULL) or apply decoded symbols (sym != NULL) */

@@ -3,6 +3,9 @@
 restatement oracle/rans_ref.c through `encode_fn`).  The format is this repo's own (SURVEY 8f-3:
 "changes the wire format -> must be opt-in"), so there is no reference to pin it against: the
 test is that the GPU kernels produce exactly these bytes and that both directions round-trip.
+A lane whose stream carries an escape of more than 8 nibbles is corrupt: rans_py.Decoder raises
+ValueError there, the device decoder sets DCVC_DRANS_BAD_STREAM, the host decoder returns
+DCVC_RANS_E_STREAM -- the same limit in all four decoders.
 """
 import struct
 

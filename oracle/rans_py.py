@@ -36,6 +36,12 @@ def encode(symbol_batches):
                 recs.append((val, val + 1, True))
                 for j in range(nb):
                     recs.append(((raw >> (4 * j)) & 15, 0, True))
+    return flush_records(recs)
+
+
+def flush_records(recs):
+    """(start, freq, bypass) records in decode order -> bytes (rans_interface.cpp:147-172).  Tests
+    also call it with forged records to build streams no encoder emits."""
     x = L
     words = []
     for start, freq, bypass in reversed(recs):
@@ -92,6 +98,8 @@ class Decoder:
                 while val == 15:
                     val = self._bits()
                     nb += val
+                if nb > 8:  # a 32-bit escape value has at most 8 nibbles: corrupt stream
+                    raise ValueError("corrupt stream: escape of %d nibbles" % nb)
                 raw = 0
                 for j in range(nb):
                     raw |= self._bits() << (4 * j)

@@ -162,6 +162,7 @@ void ref_dec_decode_stream(ref_decoder *d, const int32_t *indexes, size_t n, con
             int32_t nb = val;
             while (val == MAX_BYPASS) { val = (int32_t)dec_get_bits(d, BYPASS_BITS); nb += val; }
             int32_t raw = 0;
+            if (nb > 8) nb = 8;  /* corrupt stream (a 32-bit value has 8 nibbles): the reference is undefined here */
             for (int j = 0; j < nb; ++j) { val = (int32_t)dec_get_bits(d, BYPASS_BITS); raw |= val << (j * BYPASS_BITS); }
             value = raw >> 1;
             if (raw & 1) value = -value - 1; else value += max_value;

@@ -37,24 +37,46 @@ def nets(request):
     return d, i
 
 
+def _plane_report(got_planes, fx, prefix, report):
+    """Integer planes of one picture against the planes the REFERENCE produced for it (make_golden.py
+    `planes`): exact mismatch count per plane.  A symbol is round(float), an index a step function of
+    a float scale, so a plane can differ only where this implementation's fp32 sums land on the other
+    side of a rounding tie / bin edge than the reference's (different summation order); with
+    bit-identical floats they are equal (test_build_indexes_bit_exact_against_reference_planes,
+    test_dual_prior_matches_oracle)."""
+    for tag, t in got_planes.items():
+        want = fx[prefix + tag]
+        got = t.cpu().numpy().reshape(want.shape).astype(np.int64)
+        diff = got != want.astype(np.int64)
+        report[prefix + tag] = (int(diff.sum()), diff.size, int(np.abs(got - want)[diff].max()) if diff.any() else 0)
+
+
 def _close(got, want, tol=TOL, msg=""):
     got = got.detach().cpu().numpy() if torch.is_tensor(got) else np.asarray(got)
     np.testing.assert_allclose(got, want, rtol=tol, err_msg=msg)
 
 
-@pytest.mark.parametrize("name,h,w,n_p,seed", [("seq_64", 64, 64, 2, 0), ("seq_128", 128, 128, 2, 1),
-                                               ("seq_192x320", 192, 320, 1, 3), ("seq_256", 256, 256, 2, 2)])
-def test_estimate_path_matches_reference_fixtures(nets, name, h, w, n_p, seed):
-    d, i = nets
-    fx = golden(name)
-    fr = frames(seed, n_p + 1, h, w)
-    xs = [torch.from_numpy(fr[t : t + 1]).cuda() for t in range(n_p + 1)]
+def _check_sequence(d, i, fx, xs, n_p, name, plane_bound):
+    """I picture + n_p P pictures through the estimate path (scalars, DPB statistics) and through
+    compress (integer planes) against a fixture produced by the REFERENCE (tests/golden/make_golden*.py)."""
+    h, w = xs[0].shape[-2:]
+    report = {}
+    vi = i.compress(xs[0], 1.0)["_views"]
+    _plane_report({"sym_z": vi["sym_z"], "sym_y0": vi["r"]["sym"][0], "sym_y1": vi["r"]["sym"][1],
+                   "idx_y0": vi["r"]["idx"][0], "idx_y1": vi["r"]["idx"][1]}, fx, "i_", report)
     ri = i(xs[0], 1.0)
     for k in ("mse", "bpp", "bpp_y", "bpp_z"):
         _close(ri[k], fx[f"i_{k}"], msg="i_" + k)
     assert abs(ri["bit"] - float(fx["i_bit"])) <= TOL * float(fx["i_bit"])
+    if "i_xhat_mid" in fx:
+        np.testing.assert_allclose(ri["x_hat"][..., 512:576, 960:1024].cpu().numpy(), fx["i_xhat_mid"], atol=2e-4)
     dpb = {"ref_frame": ri["x_hat"], "ref_feature": None, "ref_y": None, "ref_mv_y": None}
     for t in range(1, n_p + 1):
+        v = d.compress(xs[t], dpb, 1.0, 1.0)["_views"]  # same analysis as the estimate path, planes kept
+        _plane_report({"sym_mv_z": v["sym_mv_z"], "sym_mv_y0": v["r_mv"]["sym"][0], "sym_mv_y1": v["r_mv"]["sym"][1],
+                       "idx_mv_y0": v["r_mv"]["idx"][0], "idx_mv_y1": v["r_mv"]["idx"][1], "sym_z": v["sym_z"],
+                       "sym_y0": v["r_y"]["sym"][0], "sym_y1": v["r_y"]["sym"][1], "idx_y0": v["r_y"]["idx"][0],
+                       "idx_y1": v["r_y"]["idx"][1]}, fx, f"p{t}_", report)
         r = d.forward_one_frame(xs[t], dpb, 1.0, 1.0)
         dpb = r["dpb"]
         p = f"p{t}_"
@@ -64,7 +86,7 @@ def test_estimate_path_matches_reference_fixtures(nets, name, h, w, n_p, seed):
             _close(r[k], fx[p + k], msg=p + k)
         psnr_got = 10 * np.log10(1.0 / r["mse"].item())
         psnr_ref = 10 * np.log10(1.0 / float(fx[p + "mse"][0]))
-        assert abs(psnr_got - psnr_ref) < 1e-3
+        assert abs(psnr_got - psnr_ref) <= TOL * max(abs(psnr_ref), 1.0), (psnr_got, psnr_ref)
         for k, v in dpb.items():
             # mean / std tightly; the abs-max is a single element and moves when one symbol rounds
             # the other way (summation-order noise of ~1e-7 is enough)
@@ -78,6 +100,49 @@ def test_estimate_path_matches_reference_fixtures(nets, name, h, w, n_p, seed):
         assert set(r) >= {"bpp_mv_y", "bpp_mv_z", "bpp_y", "bpp_z", "bpp", "me_mse", "mse", "dpb", "bit", "bit_y",
                           "bit_z", "bit_mv_y", "bit_mv_z"}
         assert r["dpb"]["ref_feature"].shape == (1, 64, h, w) and r["dpb"]["ref_y"].shape == (1, 96, h // 16, w // 16)
+    # plane-by-plane verdict against the reference's own integer planes
+    print(f"\n[{name} {d.engine().precision}] mismatching elements per plane (count / size, max |delta|):")
+    for k, (bad, n, mx) in report.items():
+        print(f"  {k:14s} {bad:6d} / {n:8d}  max {mx}")
+    for k, (bad, n, mx) in report.items():
+        if k.startswith("i_"):
+            # I picture: a flipped element is a rounding tie -> the integer moves by exactly one step
+            assert mx <= 1, (k, bad, mx)
+        # Planes are integers derived from floats (round / bin edge).  This implementation sums a
+        # convolution in a different order than the reference's CPU kernels (~1e-7 relative), so a
+        # latent within that distance of a tie lands on the other side; later planes of a P picture
+        # are conditioned on earlier ones (dual prior, DPB), so one flip moves its neighbours too.
+        # Bound: `plane_bound` of a plane's elements; observed counts are printed above and recorded
+        # in DESIGN.md section 2.  With bit-identical float inputs the planes are identical
+        # (test_build_indexes_bit_exact_against_reference_planes, test_dual_prior_matches_oracle).
+        assert bad <= max(2, int(n * plane_bound)), (k, bad, n)
+
+
+@pytest.mark.parametrize("name,h,w,n_p,seed", [("seq_64", 64, 64, 2, 0), ("seq_128", 128, 128, 2, 1),
+                                               ("seq_192x320", 192, 320, 1, 3), ("seq_256", 256, 256, 2, 2)])
+def test_estimate_path_matches_reference_fixtures(nets, name, h, w, n_p, seed):
+    d, i = nets
+    fr = frames(seed, n_p + 1, h, w)
+    xs = [torch.from_numpy(fr[t : t + 1]).cuda() for t in range(n_p + 1)]
+    _check_sequence(d, i, golden(name), xs, n_p, name, plane_bound=2e-3)
+
+
+def test_bench_size_matches_reference_fixture(nets):
+    """BASELINE configs[1]'s picture size, 1920x1080 zero-padded to 1088x1920 (video_coder.py:111-117),
+    I + 2 P pictures against tests/golden/seq_1088x1920.npz, which make_golden_1080p.py produced by
+    running the reference itself on the CPU: bpp / mse / PSNR within 1e-4 in BOTH arithmetic modes,
+    integer planes counted against the reference's planes."""
+    from vcm_ts_amd.pipeline import pad_frame
+
+    d, i = nets
+    fx = golden("seq_1088x1920")
+    fr = frames(int(fx["seed"]), 3, int(fx["height"]), int(fx["width"]))
+    xs = [pad_frame(torch.from_numpy(fr[t : t + 1])).cuda() for t in range(3)]
+    assert xs[0].shape == (1, 3, 1088, 1920)
+    _check_sequence(d, i, fx, xs, 2, "seq_1088x1920", plane_bound=5e-3)
+    d.engine().release()
+    i.engine().release()
+    torch.cuda.empty_cache()
 
 
 def test_batch_of_rate_points_matches_reference(nets):

@@ -198,6 +198,39 @@ def test_se_gate(eng):
     torch.testing.assert_close(gate.cpu().reshape(2, 32), want, rtol=1e-5, atol=1e-6)
 
 
+def test_build_indexes_bit_exact_against_reference_planes(eng):
+    """GaussianEncoder.build_indexes (entropy_models.py:264-268) on the device, integer-equal to what
+    the REFERENCE produced: its sweep over bin edges / zeros / negatives (tables.npz) and the index
+    planes it derived from its own scale planes in every seq_*.npz; plus every fp32 value within 3 ulp
+    of each of the 255 bin edges and 4M random scales against the oracle (which test_oracle_golden
+    pins to the same fixtures)."""
+    from vcm_ts_amd.entropy import scale_index_edges
+
+    fx = golden("tables")
+    s = torch.from_numpy(fx["idx_sweep_in"]).cuda()
+    for dist, key in (("laplace", "idx_sweep_laplace"), ("gaussian", "idx_sweep_gauss")):
+        np.testing.assert_array_equal(eng.scale_indexes(s, dist).cpu().numpy(), fx[key])
+    n_planes = 0
+    for name in ("seq_64", "seq_128", "seq_192x320", "seq_256"):
+        sq = golden(name)
+        for k in sq.files:
+            if "scale_" not in k:
+                continue
+            dist = "gaussian" if k.startswith("i_") else "laplace"
+            got = eng.scale_indexes(torch.from_numpy(sq[k]).cuda(), dist).cpu().numpy()
+            np.testing.assert_array_equal(got.astype(np.int16), sq[k.replace("scale_", "idx_")], err_msg=f"{name}:{k}")
+            n_planes += 1
+    assert n_planes >= 10
+    g = torch.Generator().manual_seed(9)
+    for dist in ("laplace", "gaussian"):
+        eb = scale_index_edges(dist)[:-1].view(torch.int32)
+        near = torch.cat([(eb + d).view(torch.float32) for d in range(-3, 4)])
+        rnd = torch.exp(torch.empty(4_000_000).uniform_(-13.0, 6.0, generator=g))
+        for t in (near, rnd):
+            np.testing.assert_array_equal(eng.scale_indexes(t.cuda(), dist).cpu().numpy(),
+                                          R.scale_indexes(t.clone(), dist).numpy())
+
+
 @pytest.mark.parametrize("dist,C", [("laplace", 64), ("gaussian", 192)])
 def test_dual_prior_matches_oracle(eng, dist, C):
     """Encoder kernels (estimate + symbol planes) against oracle.dual_prior with the spatial
@@ -245,9 +278,8 @@ def test_dual_prior_matches_oracle(eng, dist, C):
         np.testing.assert_array_equal(sym[k].cpu().numpy().reshape(N, C // 2, H, W), qw.numpy().astype(np.int32))
         want_idx = R.scale_indexes(sw, dist).numpy()
         got_idx = idx[k].cpu().numpy().reshape(N, C // 2, H, W)
-        # the float->int hinge: identical except where logf lands within 1 ulp of a bin edge
-        assert (got_idx != want_idx).mean() < 1e-3
-        assert np.abs(got_idx - want_idx).max() <= 1
+        # bit-exact: the kernel counts the reference's own fp32 bin edges (no device logarithm)
+        np.testing.assert_array_equal(got_idx, want_idx)
     # params buffer after step 0 = [y_hat_0_0 | y_hat_1_1 | means | scales | q_step]
     # decoder: same indexes, then apply the encoder's symbols -> identical y_hat, bit for bit
     y_hat2 = eng.fbuf("dp/yh2", n)

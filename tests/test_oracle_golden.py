@@ -73,6 +73,34 @@ def test_batch_of_rate_points():
     _run_sequence("seq_64_b2", 64, 64, 2, 4, batch=2)
 
 
+def test_bench_size_fixture_pins_oracle():
+    """The oracle at BASELINE's picture size (1088x1920) against the fixture the reference produced
+    there (tests/golden/make_golden_1080p.py): the I picture and the first P picture (~45 s of CPU;
+    the second P picture of the fixture is covered by the GPU suite only)."""
+    import torch.nn.functional as F
+
+    fx = golden("seq_1088x1920")
+    wd, wi = oracle_weights("dmc"), oracle_weights("intra")
+    fr = torch.from_numpy(frames(int(fx["seed"]), 2, int(fx["height"]), int(fx["width"])))
+    xs = F.pad(fr, (0, 0, 0, 8))
+    with torch.no_grad():
+        ri = R.intra_forward(wi, xs[0:1], 1.0)
+        for k in ("mse", "bpp", "bpp_y", "bpp_z"):
+            np.testing.assert_allclose(ri[k].numpy(), fx[f"i_{k}"], rtol=RTOL)
+        for tag, sym, sc in R.intra_symbol_planes(ri["_inter"]):
+            np.testing.assert_array_equal(sym.numpy().astype(np.int16), fx[f"i_sym_{tag}"])
+            if sc is not None:
+                np.testing.assert_array_equal(R.scale_indexes(sc, "gaussian").numpy().astype(np.int16), fx[f"i_idx_{tag}"])
+        dpb = {"ref_frame": ri["x_hat"], "ref_feature": None, "ref_y": None, "ref_mv_y": None}
+        r = R.dmc_forward_one_frame(wd, xs[1:2], dpb, 1.0, 1.0)
+        for k in ("bpp_mv_y", "bpp_mv_z", "bpp_y", "bpp_z", "bpp", "me_mse", "mse"):
+            np.testing.assert_allclose(r[k].numpy(), fx["p1_" + k], rtol=RTOL, err_msg=k)
+        for tag, sym, sc in R.dmc_symbol_planes(r["_inter"]):
+            np.testing.assert_array_equal(sym.numpy().astype(np.int16), fx[f"p1_sym_{tag}"], err_msg=tag)
+            if sc is not None:
+                np.testing.assert_array_equal(R.scale_indexes(sc).numpy().astype(np.int16), fx[f"p1_idx_{tag}"])
+
+
 def test_tables_match_reference():
     fx = golden("tables")
     for tag, dist in (("dmc", "laplace"), ("intra", "gaussian")):

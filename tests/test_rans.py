@@ -184,6 +184,34 @@ def test_error_codes(laplace_tables):
         dec.set_stream(b"abc")
 
 
+def test_corrupt_escape_count_is_rejected(laplace_tables):
+    """A stream whose escape announces more than 8 raw nibbles cannot come from any encoder (a 32-bit
+    value has 8): the product decoder must return DCVC_RANS_E_STREAM instead of shifting an int32 by
+    >= 32 bits (rans.cpp), and the Python oracle must refuse it the same way.  The stream is built by
+    the oracle's record writer with a forged count nibble."""
+    cdf, ln, off = laplace_tables
+    row = 3
+    sentinel = int(ln[row]) - 2
+    start, freq = int(cdf[row][sentinel]), int(cdf[row][sentinel + 1]) - int(cdf[row][sentinel])
+    # decode order: sentinel symbol, count nibble 12, then 12 raw nibbles
+    recs = [(start, freq, False), (12, 0, True)] + [(5, 0, True)] * 12
+    data = rans_py.flush_records(recs)
+    dec = E.RansDecoder()
+    dec.set_stream(data)
+    with pytest.raises(E.RansError):
+        dec.decode_stream(np.array([row], np.int32), cdf, ln, off)
+    with pytest.raises(ValueError):
+        rans_py.Decoder(data).decode([row], cdf, ln, off)
+    # control: the same construction with a legal count decodes in both
+    raw = 2 * 7  # value = sentinel + 7
+    recs = [(start, freq, False), (1, 0, True), (raw, 0, True)]
+    data = rans_py.flush_records(recs)
+    dec.set_stream(data)
+    want = sentinel + 7 + int(off[row])
+    assert dec.decode_stream(np.array([row], np.int32), cdf, ln, off).tolist() == [want]
+    assert rans_py.Decoder(data).decode([row], cdf, ln, off) == [want]
+
+
 def test_flush_resets_like_reset(laplace_tables):
     cdf, ln, off = laplace_tables
     enc = E.BufferedRansEncoder()

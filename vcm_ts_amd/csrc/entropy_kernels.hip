@@ -142,16 +142,38 @@ __global__ void symbols_to_nhwc_kernel(const int32_t *__restrict__ sym, float *_
     out[pix * out_cs + c] = (float)sym[((n * C + c) * H + y) * (int64_t)W + x];
 }
 
-__device__ __forceinline__ int32_t scale_index(float s, float lmin, float lstep) {
-    s = fmaxf(s, 1e-5f);
-    float v = (logf(s) - lmin) / lstep;
-    v = fminf(fmaxf(v, 0.f), 255.f);
-    return (int32_t)v;  // truncation toward zero like Tensor.int()
+// GaussianEncoder.build_indexes (entropy_models.py:264-268) without a device logarithm: the index is
+// a non-decreasing step function of the scale, so it equals the number of bin edges <= s, where
+// edge[k-1] is the smallest fp32 scale whose reference (torch-CPU fp32) index is >= k.  The 255
+// edges are found on the host by bisection over the float's bit pattern with the reference formula
+// itself (vcm_ts_amd/entropy.py scale_index_edges), so encoder, decoder and reference agree bit
+// for bit.  `edges` has 256 entries, the last one +inf.  Scales below 1e-5 (incl. negatives) sit
+// under every edge -> 0, like the reference's clamp; a NaN compares false everywhere -> 0.
+__device__ __forceinline__ int32_t scale_index(float s, const float *edges) {
+    int lo = 0;  // invariant: edges[0..lo) <= s
+#pragma unroll
+    for (int step = 128; step >= 1; step >>= 1)
+        if (edges[lo + step - 1] <= s) lo += step;
+    return lo;
+}
+
+__global__ void scale_indexes_kernel(const float *__restrict__ scales, int32_t *__restrict__ idx, int64_t n,
+                                     const float *__restrict__ edges_g) {
+    __shared__ float edges[256];
+    edges[threadIdx.x] = edges_g[threadIdx.x];
+    __syncthreads();
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid < n) idx[gid] = scale_index(scales[gid], edges);
 }
 
 // mode 0: encoder (needs y); mode 1: decoder index pass; mode 2: decoder apply pass
 template <int MODE>
 __global__ void dual_prior_kernel(const dcvc_dual_prior_args a, int64_t total) {
+    __shared__ float edges[256];
+    if (MODE != 2) {  // the apply pass of the decoder writes no indexes
+        edges[threadIdx.x] = a.idx_edges ? a.idx_edges[threadIdx.x] : 0.f;
+        __syncthreads();
+    }
     const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= total) return;
     const int C = a.C, Ch = C >> 1;
@@ -183,7 +205,7 @@ __global__ void dual_prior_kernel(const dcvc_dual_prior_args a, int64_t total) {
             pr[2 * C + c] = fu[C + c];
             pr[3 * C + c] = qs;
         }
-        if (active) a.idx[s_i] = scale_index(sc, a.log_scale_min, a.log_scale_step);
+        if (active) a.idx[s_i] = scale_index(sc, edges);
         return;
     }
     float hat = 0.f;
@@ -197,7 +219,7 @@ __global__ void dual_prior_kernel(const dcvc_dual_prior_args a, int64_t total) {
             if (a.y_q) a.y_q[e] = q;
             if (a.scales_hat) a.scales_hat[e] = sc;
             if (a.sym) a.sym[s_i] = (int32_t)q;
-            if (a.idx) a.idx[s_i] = scale_index(sc, a.log_scale_min, a.log_scale_step);
+            if (a.idx) a.idx[s_i] = scale_index(sc, edges);
         } else {
             q = (float)a.sym[s_i];
         }
@@ -351,15 +373,24 @@ static int dual_prior_check(const dcvc_dual_prior_args *a) {
     return DCVC_OK;
 }
 
+extern "C" int dcvc_scale_indexes(const float *scales, int32_t *idx, int64_t n, const float *idx_edges, void *stream) {
+    if (!scales || !idx || !idx_edges || n < 0) return DCVC_E_ARG;
+    if (n == 0) return DCVC_OK;
+    hipLaunchKernelGGL(scale_indexes_kernel, dim3(nblk(n, 256)), dim3(256), 0, (hipStream_t)stream, scales, idx, n,
+                       idx_edges);
+    RET_LAUNCH();
+}
+
 extern "C" int dcvc_dual_prior_enc(const dcvc_dual_prior_args *a, void *stream) {
-    if (dual_prior_check(a) || !a->y) return DCVC_E_ARG;
+    if (dual_prior_check(a) || !a->y || (a->idx && !a->idx_edges)) return DCVC_E_ARG;
     const int64_t total = (int64_t)a->N * a->H * a->W * a->C;
     hipLaunchKernelGGL(dual_prior_kernel<0>, dim3(nblk(total, 256)), dim3(256), 0, (hipStream_t)stream, *a, total);
     RET_LAUNCH();
 }
 
 extern "C" int dcvc_dual_prior_dec_index(const dcvc_dual_prior_args *a, void *stream) {
-    if (!a || !a->fusion || !a->params || !a->idx || (a->C & 1) || (a->step == 1 && !a->spatial)) return DCVC_E_ARG;
+    if (!a || !a->fusion || !a->params || !a->idx || !a->idx_edges || (a->C & 1) || (a->step == 1 && !a->spatial))
+        return DCVC_E_ARG;
     const int64_t total = (int64_t)a->N * a->H * a->W * a->C;
     hipLaunchKernelGGL(dual_prior_kernel<1>, dim3(nblk(total, 256)), dim3(256), 0, (hipStream_t)stream, *a, total);
     RET_LAUNCH();

@@ -188,11 +188,16 @@ extern "C" int dcvc_rans_decoder_decode_stream(dcvc_rans_decoder *d, const int32
                 if (!take_nibble(d, x, nb)) return DCVC_RANS_E_STREAM;
                 cnt += nb;
             }
-            int32_t raw = 0;
+            // a 32-bit escape value needs at most 8 nibbles; a larger count can only come from a
+            // corrupt stream (and would shift an int32 by >= 32 bits).  The device decoder applies
+            // the same limit (rans_device.hip).
+            if (cnt > 8) return DCVC_RANS_E_STREAM;
+            uint32_t raw_u = 0;
             for (int32_t j = 0; j < cnt; ++j) {
                 if (!take_nibble(d, x, nb)) return DCVC_RANS_E_STREAM;
-                raw |= nb << (j * kNibbleBits);
+                raw_u |= (uint32_t)nb << (j * kNibbleBits);
             }
+            const int32_t raw = (int32_t)raw_u;
             v = raw >> 1;
             v = (raw & 1) ? -v - 1 : v + sentinel;
         }

@@ -341,8 +341,10 @@ __global__ __launch_bounds__(STAGE) void drans_decode_kernel(const uint32_t *__r
                     nb = nibble();
                     c += nb;
                 }
-                int raw = 0;
-                for (int j = 0; j < c && j < 8; ++j) raw |= nibble() << (j * kNibbleBits);
+                if (c > 8) bad |= DCVC_DRANS_BAD_STREAM;  // a 32-bit escape has 8 nibbles (same limit as rans.cpp)
+                uint32_t raw_u = 0;
+                for (int j = 0; j < c && j < 8; ++j) raw_u |= (uint32_t)nibble() << (j * kNibbleBits);
+                const int raw = (int)raw_u;
                 v = raw >> 1;
                 v = (raw & 1) ? -v - 1 : v + sentinel;
             }

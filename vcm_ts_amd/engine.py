@@ -92,6 +92,7 @@ class Engine:
         self.profile = None  # set to {} to time every conv launch with HIP events (bench.py)
         self.profile_detail = None
         self.tape = None     # grad.Tape while a training-mode forward is being recorded
+        self._edges = {}     # distribution -> device (256,) fp32 bin edges of build_indexes
 
     # ------------------------------------------------------------------ memory
     def stream(self):
@@ -395,9 +396,7 @@ class Engine:
         if out is not None:
             a.out, a.out_cs = out.ptr, out.cs
         a.N, a.H, a.W, a.C, a.step = fusion.N, fusion.H, fusion.W, Cc, step
-        smin = 0.01 if distribution == "laplace" else 0.11
-        a.log_scale_min = math.log(smin)
-        a.log_scale_step = (math.log(64.0) - math.log(smin)) / 255
+        a.idx_edges = self.index_edges(distribution).data_ptr()
         fn = {"enc": self.L.dcvc_dual_prior_enc, "dec_index": self.L.dcvc_dual_prior_dec_index,
               "dec_apply": self.L.dcvc_dual_prior_dec_apply}[mode]
         lib.check(fn(C.byref(a), self.stream()), "dual_prior_" + mode)
@@ -405,6 +404,25 @@ class Engine:
         if mode == "enc":
             self._rec("dual_prior", step, y, fusion, spatial, params, y_hat, y_res, scales_hat, out, q_basic, q_scale,
                       qkey)
+
+    def index_edges(self, distribution) -> torch.Tensor:
+        """Device copy of entropy.scale_index_edges: the 255 fp32 bin edges of build_indexes."""
+        t = self._edges.get(distribution)
+        if t is None:
+            from .entropy import scale_index_edges
+
+            t = scale_index_edges(distribution).to(self.device)
+            self._edges[distribution] = t
+        return t
+
+    def scale_indexes(self, scales: torch.Tensor, distribution="laplace") -> torch.Tensor:
+        """GaussianEncoder.build_indexes (entropy_models.py:264-268) of a flat fp32 device tensor."""
+        scales = scales.contiguous()
+        idx = torch.empty(scales.numel(), dtype=torch.int32, device=self.device)
+        lib.check(self.L.dcvc_scale_indexes(scales.data_ptr(), idx.data_ptr(), scales.numel(),
+                                            self.index_edges(distribution).data_ptr(), self.stream()), "scale_indexes")
+        self.calls += 1
+        return idx.view(scales.shape)
 
     def _scratch(self, N):
         return self.fbuf("reduce_scratch", N * 1024, scratch=True)

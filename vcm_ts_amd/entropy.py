@@ -154,6 +154,47 @@ def scale_log_params(distribution: str):
     return lmin, (math.log(SCALE_MAX) - lmin) / (SCALE_LEVELS - 1)
 
 
+def reference_scale_indexes(scales: torch.Tensor, distribution: str) -> torch.Tensor:
+    """GaussianEncoder.build_indexes exactly as the reference evaluates it (entropy_models.py:264-268:
+    fp32 torch-CPU tensor ops, Python-double constants).  Host-side; used to derive the bin edges."""
+    lmin, lstep = scale_log_params(distribution)
+    scales = torch.maximum(scales, torch.zeros_like(scales) + 1e-5)
+    indexes = (torch.log(scales) - lmin) / lstep
+    return indexes.clamp_(0, SCALE_LEVELS - 1).int()
+
+
+_EDGE_CACHE = {}
+
+
+def scale_index_edges(distribution: str) -> torch.Tensor:
+    """(256,) fp32: edge[k-1] = the smallest fp32 scale whose reference index is >= k (k = 1..255),
+    edge[255] = +inf, so that index(s) = #{edges <= s} reproduces build_indexes bit for bit without a
+    device logarithm (the kernels' logf differs from torch-CPU's by an ulp next to a bin edge).  Found
+    by bisection over the float's bit pattern -- positive floats order like their int32 bits -- with
+    the reference formula itself, all 255 edges at once."""
+    if distribution in _EDGE_CACHE:
+        return _EDGE_CACHE[distribution]
+    k = torch.arange(1, SCALE_LEVELS + 1, dtype=torch.int32)          # 256 lanes; the last is a dummy
+    lo = torch.full((SCALE_LEVELS,), 1e-5, dtype=torch.float32).view(torch.int32).clone()    # index 0 < k
+    hi = torch.full((SCALE_LEVELS,), 128.0, dtype=torch.float32).view(torch.int32).clone()   # index 255
+    for _ in range(32):
+        mid = lo + (hi - lo) // 2
+        ge = reference_scale_indexes(mid.view(torch.float32).clone(), distribution) >= k
+        hi = torch.where(ge, mid, hi)
+        lo = torch.where(ge, lo, mid)
+    edges = hi.view(torch.float32).clone()
+    edges[SCALE_LEVELS - 1] = float("inf")
+    # the construction assumes a monotone index; verify it on both sides of every edge
+    below = (hi - 1).view(torch.float32).clone()
+    kk = k[:-1]
+    if not (torch.equal(reference_scale_indexes(edges[:-1].clone(), distribution), kk)
+            and torch.equal(reference_scale_indexes(below[:-1], distribution), kk - 1)
+            and bool((edges[1:] > edges[:-1]).all())):
+        raise RansError("build_indexes is not a monotone step function on this host; bin edges undefined")
+    _EDGE_CACHE[distribution] = edges
+    return edges
+
+
 def _dist(distribution, scale):
     loc = torch.zeros_like(scale)
     if distribution == "laplace":
@@ -292,6 +333,7 @@ class DeviceCoder:
         self.init_host = torch.tensor([1, 0, 1], dtype=torch.int32).pin_memory()
         self.magic = torch.tensor([int.from_bytes(DRANS_MAGIC, "little")], dtype=torch.int32).pin_memory()
         self.flip = 0
+        self._slot_owner = [None, None]   # DevicePayload that last wrote payloads[k] / state_host[k]
         self.scratch = None
         self.words = 0
 
@@ -312,6 +354,11 @@ class DeviceCoder:
         return a, self.state.data_ptr() + 8 * self.sel
 
     def begin(self):
+        # two payload buffers / pinned state words alternate: the picture that last used this slot must
+        # have been fetched (DevicePayload.finish) before the slot is rewritten, or its bytes are lost
+        owner = self._slot_owner[self.flip]
+        if owner is not None and owner._bytes is None:
+            raise RuntimeError("more than two device-coded pictures are pending: finish() the oldest first")
         self.payload = self.payloads[self.flip]
         self.payload[:1].copy_(self.magic, non_blocking=True)
         self.state.copy_(self.init_host, non_blocking=True)
@@ -337,7 +384,9 @@ class DeviceCoder:
         host.copy_(self.state, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(self.device))
-        return DevicePayload(self, self.payload, host, ev, 2 * self.sel)
+        p = DevicePayload(self, self.payload, host, ev, 2 * self.sel)
+        self._slot_owner[self.flip ^ 1] = p
+        return p
 
     # -- decoder
     DEC_SLOTS = 4

@@ -80,7 +80,7 @@ class DualPriorArgs(C.Structure):
         ("y_hat", C.c_void_p), ("y_q", C.c_void_p), ("y_res", C.c_void_p), ("scales_hat", C.c_void_p),
         ("sym", C.c_void_p), ("idx", C.c_void_p), ("out", C.c_void_p), ("out_cs", C.c_int32),
         ("q_basic", C.c_void_p), ("q_scale", C.c_void_p), ("N", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
-        ("C", C.c_int32), ("step", C.c_int32), ("log_scale_min", C.c_float), ("log_scale_step", C.c_float),
+        ("C", C.c_int32), ("step", C.c_int32), ("idx_edges", C.c_void_p),
     ]
 
 
@@ -138,6 +138,7 @@ _SIGS = {
     "dcvc_scale_channels": [vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, vp],
     "dcvc_round_symbols": [vp, i32, vp, i32, vp, i32, i32, i32, i32, vp],
     "dcvc_symbols_to_nhwc": [vp, vp, i32, i32, i32, i32, i32, vp],
+    "dcvc_scale_indexes": [vp, vp, i64, vp, vp],
     "dcvc_dual_prior_enc": [C.POINTER(DualPriorArgs), vp],
     "dcvc_dual_prior_dec_index": [C.POINTER(DualPriorArgs), vp],
     "dcvc_dual_prior_dec_apply": [C.POINTER(DualPriorArgs), vp],
