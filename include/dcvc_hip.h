@@ -47,6 +47,11 @@ extern "C" {
 #define DCVC_OK 0
 #define DCVC_E_ARG (-1)      /* bad argument (shape, alignment, unsupported kernel size) */
 #define DCVC_E_LAUNCH (-2)   /* hipGetLastError() after the launch was not hipSuccess */
+#define DCVC_E_RANGE (-3)    /* a weight does not fit the split-fp16 representation (|w| >= 1023.5): the packed
+                                buffer holds the clamped value; use DCVC_PREC_FP32 for this layer */
+
+/* bits of the optional device status word of the split-fp16 kernels */
+#define DCVC_STATUS_ACT_SATURATED 1  /* an activation with |v| > 8188 was clamped while being stored split */
 
 #define DCVC_MAX_SEG 3
 
@@ -105,6 +110,57 @@ int dcvc_conv_pack_weights(const float *w, const float *b, int32_t Cout, int32_t
                            float *bpack);
 
 int dcvc_conv2d(const dcvc_conv_args *a, void *stream);
+
+/* ---- pre-split activations ("S16") --------------------------------------------------------
+ * The fast form of DCVC_PREC_FP16X3 for 3x3 stride-1 layers whose inputs were produced by another
+ * convolution (vcm_ts_amd/csrc/conv_s16.hip).  An S16 tensor has the geometry of the fp32 NHWC
+ * tensor it mirrors -- pixel stride cs*4 bytes, C % 16 == 0, cs % 16 == 0, base 64-byte aligned --
+ * but every 16-channel chunk of a pixel is stored as 64 bytes [16 x fp16 hi | 16 x fp16 lo] with
+ * hi = fp16(8 v), lo = fp16(8 v - hi): exactly the operand split dcvc_conv2d performs on load, done
+ * once by the producer instead of by every consumer.  Same products, same accumulation order:
+ * results are bit-identical to dcvc_conv2d(DCVC_PREC_FP16X3) on the fp32 tensor (tests). */
+#define DCVC_FMT_F32 0
+#define DCVC_FMT_S16 1
+
+typedef struct {
+    dcvc_seg seg[DCVC_MAX_SEG];  /* S16 inputs, walked in torch.cat order; ptr is the S16 buffer */
+    int32_t nseg;
+    int32_t N, H, W;             /* stride 1, padding 1: output size == input size */
+    const void *wpack;           /* dcvc_conv_s16_pack_weights */
+    const float *bpack;
+    int32_t ks;                  /* 3 */
+    int32_t Cout;                /* % 16 == 0 (and (Cout/4) % 16 == 0 with pixel_shuffle) */
+    int32_t Cout_pad;            /* as returned by dcvc_conv_s16_pack_bytes */
+    /* result = res2 + (act(conv + bias) + res * gate), as dcvc_conv2d; written to either or both of */
+    float *out;                  /* fp32 NHWC (out_cs), or NULL */
+    int32_t out_cs;
+    int32_t out_act;             /* 0 none, 1 LeakyReLU(out_slope), 2 clamp [0,1] */
+    float out_slope;
+    void *out16;                 /* S16 tensor (out16_cs) holding act16(result), or NULL */
+    int32_t out16_cs;
+    int32_t out16_act;           /* 0: the result itself; 1: LeakyReLU(out16_slope)(result), i.e. the NEXT layer's
+                                    input activation (video_net.py:82-95) applied by the producer */
+    float out16_slope;
+    int32_t pixel_shuffle;
+    const void *res;             /* optional residual, fp32 NHWC or S16 per res_fmt (may alias the same-format output) */
+    int32_t res_cs;
+    int32_t res_fmt;
+    const float *res_gate;
+    const void *res2;
+    int32_t res2_cs;
+    int32_t res2_fmt;
+    int32_t *status;             /* optional device word, OR-ed with DCVC_STATUS_* */
+} dcvc_conv_s16_args;
+
+int64_t dcvc_conv_s16_pack_bytes(int32_t Cout, int32_t ks, int32_t nseg, const int32_t *seg_C, int32_t *cout_pad);
+/* HOST function; returns DCVC_E_RANGE (buffers still written, clamped) when a weight is out of range */
+int dcvc_conv_s16_pack_weights(const float *w, const float *b, int32_t Cout, int32_t ks, int32_t nseg,
+                               const int32_t *seg_C, int32_t pixel_shuffle, void *wpack, float *bpack);
+int dcvc_conv2d_s16(const dcvc_conv_s16_args *a, void *stream);
+/* fp32 NHWC -> S16 (optionally through LeakyReLU(slope)) and back; for tensors no convolution produced */
+int dcvc_s16_pack(const float *src, int32_t src_cs, void *out, int32_t out_cs, int64_t npix, int32_t C, int32_t act,
+                  float slope, int32_t *status, void *stream);
+int dcvc_s16_unpack(const void *src, int32_t src_cs, float *out, int32_t out_cs, int64_t npix, int32_t C, void *stream);
 
 /* ---- resampling ------------------------------------------------------------------------ */
 /* out(n,y,x,c) = bilinear(src(n,.,.,c), x + flow(n,y,x,0), y + flow(n,y,x,1)), border clamp */
