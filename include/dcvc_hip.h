@@ -113,12 +113,14 @@ int dcvc_conv2d(const dcvc_conv_args *a, void *stream);
 
 /* ---- pre-split activations ("S16") --------------------------------------------------------
  * The fast form of DCVC_PREC_FP16X3 for 3x3 stride-1 layers whose inputs were produced by another
- * convolution (vcm_ts_amd/csrc/conv_s16.hip).  An S16 tensor has the geometry of the fp32 NHWC
- * tensor it mirrors -- pixel stride cs*4 bytes, C % 16 == 0, cs % 16 == 0, base 64-byte aligned --
- * but every 16-channel chunk of a pixel is stored as 64 bytes [16 x fp16 hi | 16 x fp16 lo] with
- * hi = fp16(8 v), lo = fp16(8 v - hi): exactly the operand split dcvc_conv2d performs on load, done
- * once by the producer instead of by every consumer.  Same products, same accumulation order:
- * results are bit-identical to dcvc_conv2d(DCVC_PREC_FP16X3) on the fp32 tensor (tests). */
+ * convolution (vcm_ts_amd/csrc/conv_s16.hip).  An S16 tensor of C channels (C % 16 == 0) is PLANAR in
+ * 16-channel chunks: element (n, c, y, x) lives in the 64-byte record
+ *     base + ((n * cs/16 + c/16) * H*W + y*W + x) * 64 = [16 x fp16 hi | 16 x fp16 lo]
+ * (cs = channels of the underlying buffer, cs % 16 == 0; a channel slice is a run of planes; base
+ * 64-byte aligned; same size in bytes as the fp32 tensor) with hi = fp16(8 v), lo = fp16(8 v - hi):
+ * exactly the operand split dcvc_conv2d performs on load, done once by the producer instead of by
+ * every consumer, in a layout where a patch row of one chunk is contiguous.  Same products, same
+ * accumulation order: results are bit-identical to dcvc_conv2d(DCVC_PREC_FP16X3) on the fp32 tensor. */
 #define DCVC_FMT_F32 0
 #define DCVC_FMT_S16 1
 
@@ -158,9 +160,10 @@ int dcvc_conv_s16_pack_weights(const float *w, const float *b, int32_t Cout, int
                                const int32_t *seg_C, int32_t pixel_shuffle, void *wpack, float *bpack);
 int dcvc_conv2d_s16(const dcvc_conv_s16_args *a, void *stream);
 /* fp32 NHWC -> S16 (optionally through LeakyReLU(slope)) and back; for tensors no convolution produced */
-int dcvc_s16_pack(const float *src, int32_t src_cs, void *out, int32_t out_cs, int64_t npix, int32_t C, int32_t act,
+int dcvc_s16_pack(const float *src, int32_t src_cs, void *out, int32_t out_cs, int32_t N, int64_t HW, int32_t C, int32_t act,
                   float slope, int32_t *status, void *stream);
-int dcvc_s16_unpack(const void *src, int32_t src_cs, float *out, int32_t out_cs, int64_t npix, int32_t C, void *stream);
+int dcvc_s16_unpack(const void *src, int32_t src_cs, float *out, int32_t out_cs, int32_t N, int64_t HW, int32_t C,
+                    void *stream);
 
 /* ---- resampling ------------------------------------------------------------------------ */
 /* out(n,y,x,c) = bilinear(src(n,.,.,c), x + flow(n,y,x,0), y + flow(n,y,x,1)), border clamp */

@@ -388,7 +388,14 @@ __global__ __launch_bounds__(256, CLASSIC_WAVES_PER_SIMD) void conv_mfma(const C
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = fminf(fmaxf(v[e], 0.f), 1.f);
                 }
-                if (a.res) v = v + (a.res_gate ? rv[m][it] * gate : rv[m][it]);
+                if (a.res) {
+                    if (a.res_gate) {  // explicit fma: the same rounding in every kernel that applies the SE gate
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaf(rv[m][it][e], gate[e], v[e]);
+                    } else {
+                        v = v + rv[m][it];
+                    }
+                }
                 if (a.res2) v = rv2[m][it] + v;
                 if (ok[m][it]) *(f32x4 *)&a.out[pix[m][it] * a.out_cs + cf] = v;
             }
@@ -436,7 +443,7 @@ __global__ __launch_bounds__(256, CLASSIC_WAVES_PER_SIMD) void conv_mfma(const C
                 else if (a.out_act == 2) v = fminf(fmaxf(v, 0.f), 1.f);
                 const size_t pix = a.ps ? ((size_t)(img * Ho + 2 * oy + dy) * Wo + 2 * ox + dx)
                                         : ((size_t)(img * Ho + oy) * Wo + ox);
-                if (a.res) v += a.res_gate ? rv[r] * gate : rv[r];
+                if (a.res) v = a.res_gate ? __builtin_fmaf(rv[r], gate, v) : v + rv[r];
                 if (a.res2) v = rv2[r] + v;
                 a.out[pix * a.out_cs + cf] = v;
             }

@@ -23,14 +23,19 @@
 //     contiguous 64-byte run per lane (4 x dwordx4) without an LDS transpose;
 //   * tiles are dealt to workgroups in per-XCD bands, so halo rows are re-read from that XCD's L2.
 //
-// S16 layout of a C-channel tensor (C % 16 == 0): pixel stride cs*4 bytes (cs = the fp32 view's
-// channel stride), and per 16-channel chunk 64 bytes = [16 x fp16 hi | 16 x fp16 lo] with
-// hi = fp16(8 v), lo = fp16(8 v - hi)  (ACT_SCALE = 8 as in conv_mfma.hip).
+// S16 layout of a C-channel tensor (C % 16 == 0): PLANAR.  Every 16-channel chunk p of image n is
+// four (H, W) planes of 16-byte entries -- slot 0: fp16 hi of channels 0-7 of the chunk, slot 1: hi
+// of channels 8-15, slot 2: lo of 0-7, slot 3: lo of 8-15 (hi = fp16(8 v), lo = fp16(8 v - hi),
+// ACT_SCALE = 8 as in conv_mfma.hip) -- i.e. exactly the 16-byte MFMA operand fragments:
+//     base + (((n * cs/16 + p) * 4 + slot) * H*W + y*W + x) * 16
+// where cs is the channel count of the underlying buffer (a channel slice = a run of planes).  A
+// lane of the accumulator owns one pixel, so a wave's store of one slot is 32 x 16 B = 512 B
+// contiguous per lane half, and a patch row of a slot is one contiguous run for the DMA.
 //
-// LDS images.  Patch: (16+2) x (32+2) pixel records of 64 B, linear in DMA order; the four 16-B
-// slots of a record [hi k0-7 | hi k8-15 | lo k0-7 | lo k8-15] are XOR-swizzled with (pixel>>2)&3
-// on the SOURCE address (LDS-DMA writes lane-linear), which makes the ds_read_b128 of 32
-// consecutive pixels conflict-free for every tap.  Filter slab: [tap][hi h0, hi h1, lo h0, lo h1]
+// LDS images.  Patch: slot-planar like the tensor, [4 slots][(16+2) x (32+2) pixels][16 B], linear
+// in DMA order (a wave-instruction copies runs of a 34-pixel patch row of one slot plane: whole
+// cache lines); consecutive lanes read consecutive 16 B, so every ds_read_b128 is conflict-free
+// without a swizzle.  Filter slab: [tap][hi h0, hi h1, lo h0, lo h1]
 // [64 output rows][8 fp16], copied linearly from the host-packed weights.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -54,7 +59,7 @@ __device__ uint4 g_zero_page[16];  // 256 B of zeros: source of out-of-picture p
 struct S16K {
     const char *seg_ptr[DCVC_MAX_SEG];
     int seg_chunks[DCVC_MAX_SEG];  // 16-channel chunks per segment
-    int seg_cs[DCVC_MAX_SEG];
+    int seg_planes[DCVC_MAX_SEG];  // planes per image of the segment's underlying buffer (cs / 16)
     int nseg, nchunks;
     int N, H, W;
     const char *wpack;
@@ -78,35 +83,46 @@ struct S16K {
 
 __device__ __forceinline__ float lrelu(float v, float slope) { return v > 0.f ? v : v * slope; }
 
+__device__ __forceinline__ void keep_alive(const f32x16 &v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" ::"v"(v));
+#endif
+}
+
 __device__ __forceinline__ void glds16(const void *g, void *l) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
                                      (__attribute__((address_space(3))) void *)l, 16, 0, 0);
 }
 
-// 16 consecutive channels of one pixel, fp32 or S16 source
-__device__ __forceinline__ void load16(const char *base, size_t pixel, int cs, int fmt, int cf, float *v) {
+// 16 consecutive channels of one pixel TIMES ACT_SCALE, from an fp32 NHWC or an S16 source.  pixel: index over
+// (n, y, x); img / pin: its image and in-image parts; hw: pixels per image.  (hi + lo is exact in fp32.)
+__device__ __forceinline__ void load16x8(const char *base, size_t pixel, int img, size_t pin, size_t hw, int cs, int fmt,
+                                         int cf, float *v) {
     if (fmt == DCVC_FMT_F32) {
         const f32x4 *p = (const f32x4 *)(base + (pixel * cs + cf) * 4);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const f32x4 t = p[i];
+            const f32x4 t = p[i] * ACT_SCALE;
             v[4 * i] = t[0], v[4 * i + 1] = t[1], v[4 * i + 2] = t[2], v[4 * i + 3] = t[3];
         }
     } else {
-        const f16x8 *p = (const f16x8 *)(base + pixel * cs * 4 + (size_t)(cf >> 4) * 64);
-        const f16x8 h0 = p[0], h1 = p[1], l0 = p[2], l1 = p[3];
+        const char *p = base + ((((size_t)img * (cs >> 4) + (cf >> 4)) * 4) * hw + pin) * 16;
+        const f16x8 h0 = *(const f16x8 *)p, h1 = *(const f16x8 *)(p + hw * 16), l0 = *(const f16x8 *)(p + hw * 32),
+                    l1 = *(const f16x8 *)(p + hw * 48);
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            v[i] = ((float)h0[i] + (float)l0[i]) * (1.f / ACT_SCALE);
-            v[8 + i] = ((float)h1[i] + (float)l1[i]) * (1.f / ACT_SCALE);
+            v[i] = (float)h0[i] + (float)l0[i];
+            v[8 + i] = (float)h1[i] + (float)l1[i];
         }
     }
 }
 
-template <int KS, int NT>
+// PROBE is 0 in the product library; tools/probes/conv_s16_probe.hip instantiates the ablations
+// (1: no DMA after the first step, 2: no MFMA phase, 4: no epilogue) to see what each phase costs.
+template <int KS, int NT, int PROBE = 0>
 __global__ __launch_bounds__(512, 2) void conv_s16_kernel(const S16K a) {
     constexpr int BH = 16, BW = 32, PAD = KS / 2, PH = BH + KS - 1, PW = BW + KS - 1, T = KS * KS, CB = 32 * NT;
-    constexpr int PSLOTS = PH * PW * 4, NWI_P = (PSLOTS + 63) / 64, PATCH_BYTES = NWI_P * 1024;
+    constexpr int NPIX = PH * PW, PSLOTS = NPIX * 4, NWI_P = (PSLOTS + 63) / 64, PATCH_BYTES = NWI_P * 1024;
     constexpr int FILT_BYTES = T * 4 * CB * 16, NWI_F = FILT_BYTES / 1024;
     constexpr int RP = (NWI_P + 7) / 8, RF = (NWI_F + 7) / 8;
     extern __shared__ __attribute__((aligned(1024))) char lds[];
@@ -135,13 +151,7 @@ __global__ __launch_bounds__(512, 2) void conv_s16_kernel(const S16K a) {
     }
     if (count == 0) return;
 
-    // ---- DMA lane geometry (tile-independent part): slot g = wi*64 + lane of the linear patch image
-    int swb[RP];
-#pragma unroll
-    for (int u = 0; u < RP; ++u) {
-        const int gs = (wave + 8 * u) * 64 + lane, q = gs >> 2;
-        swb[u] = (((gs & 3) ^ ((q >> 2) & 3)) << 4);
-    }
+    // ---- DMA lane geometry: entry gs = wi*64 + lane of the slot-planar patch image [slot][pixel][16 B]
     struct Tile {
         int blk, img, y0, x0;
     };
@@ -156,53 +166,55 @@ __global__ __launch_bounds__(512, 2) void conv_s16_kernel(const S16K a) {
         t.x0 = (r - ty * a.ntx) * BW;
         return t;
     };
-    int pixoff[RP];
+    const unsigned hw_in = (unsigned)(a.H * a.W);
+    int pixoff[RP];  // (slot * H*W + pixel) of the source entry, or -1: out of the picture -> zero page
     auto setup_dma = [&](const Tile &t) {
 #pragma unroll
         for (int u = 0; u < RP; ++u) {
-            const int gs = (wave + 8 * u) * 64 + lane, q = gs >> 2;
+            const int gs = (wave + 8 * u) * 64 + lane;
+            const int slot = gs / NPIX, q = gs - slot * NPIX;
             const int py = q / PW, px = q - py * PW;
             const int gy = t.y0 - PAD + py, gx = t.x0 - PAD + px;
             const bool ok = gs < PSLOTS && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-            pixoff[u] = ok ? gy * a.W + gx : -1;
+            pixoff[u] = ok ? (int)(slot * hw_in) + gy * a.W + gx : -1;
         }
     };
-    // chunk cg of the concatenated input -> (segment, chunk inside it)
-    auto issue_patch = [&](const Tile &t, int cg, int buf) {
+    // DMA of one step, issued round by round from inside the multiply phase (an LDS-DMA costs its wave
+    // 60-180 issue cycles: spread between the MFMAs, and at different points for the two waves of a SIMD,
+    // the partner's MFMAs cover them).  chunk cg of the concatenated input -> (segment, chunk inside it)
+    const char *dma_sp = nullptr, *dma_fp = nullptr;
+    char *dma_pd = nullptr, *dma_fd = nullptr;
+    auto dma_begin = [&](const Tile &t, int cg, int buf) {
         int s = 0, c = cg;
         while (c >= a.seg_chunks[s]) c -= a.seg_chunks[s], ++s;
-        const int cs = a.seg_cs[s];
-        const char *sp = a.seg_ptr[s] + ((size_t)t.img * a.H * a.W * cs + (size_t)c * KC) * 4;
-        char *dst = patch + buf * PATCH_BYTES;
-#pragma unroll
-        for (int u = 0; u < RP; ++u) {
-            const int wi = wave + 8 * u;
-            if (wi < NWI_P) {
-                const char *src = pixoff[u] >= 0 ? sp + (size_t)(unsigned)pixoff[u] * (unsigned)(cs * 4) + swb[u]
-                                                 : (const char *)g_zero_page + (lane & 15) * 16;
-                glds16(src, dst + wi * 1024);
-            }
-        }
+        dma_sp = a.seg_ptr[s] + (((size_t)t.img * a.seg_planes[s] + c) * 4) * ((size_t)hw_in * 16);
+        dma_fp = a.wpack + ((size_t)(t.blk * a.nchunks + cg)) * FILT_BYTES + lane * 16;
+        dma_pd = patch + buf * PATCH_BYTES;
+        dma_fd = filt + buf * FILT_BYTES;
     };
-    auto issue_filter = [&](const Tile &t, int cg, int buf) {
-        const char *src = a.wpack + ((size_t)(t.blk * a.nchunks + cg)) * FILT_BYTES + lane * 16;
-        char *dst = filt + buf * FILT_BYTES;
-#pragma unroll
-        for (int u = 0; u < RF; ++u) {
-            const int wi = wave + 8 * u;
-            if (wi < NWI_F) glds16(src + wi * 1024, dst + wi * 1024);
+    auto dma_round = [&](int u) {  // u: compile-time round index
+        const int wi = wave + 8 * u;
+        if (u < RP && wi < NWI_P) {
+            const char *src = pixoff[u] >= 0 ? dma_sp + (size_t)((unsigned)pixoff[u] * 16u)
+                                             : (const char *)g_zero_page + (lane & 15) * 16;
+            glds16(src, dma_pd + wi * 1024);
         }
+        if (u < RF && wi < NWI_F) glds16(dma_fp + wi * 1024, dma_fd + wi * 1024);
     };
+    constexpr int NR = RP > RF ? RP : RF;
+    static_assert(NR <= T, "one DMA round per tap");
 
-    // per-lane LDS read offsets: activation fragment of row m, tap (ky, kx); lo = hi ^ 32
-    const int qlane = r0 * PW + col;
+    // per-lane LDS read offsets: the hi fragment of a pixel is entry (slot hh, pixel), lo two slot planes on
+    const int plane_off = (hh * NPIX + r0 * PW + col) * 16;
     const int wlane = (hh * CB + col) * 16;
 
     Tile cur = decode(first);
     setup_dma(cur);
-    issue_patch(cur, 0, 0);
-    issue_filter(cur, 0, 0);
+    dma_begin(cur, 0, 0);
+#pragma unroll
+    for (int u = 0; u < NR; ++u) dma_round(u);
     int sbuf = 0;  // buffer (patch and filter alike) holding the step about to be multiplied
+    const int late = wave >> 2;  // waves w and w+4 share a SIMD: they issue their DMA rounds half a tap apart
 
     for (int it = 0; it < count; ++it) {
         f32x16 acc[2][NT];
@@ -219,27 +231,27 @@ __global__ __launch_bounds__(512, 2) void conv_s16_kernel(const S16K a) {
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
+            bool more = false;
             if (cg + 1 < a.nchunks) {
-                issue_patch(cur, cg + 1, sbuf ^ 1);
-                issue_filter(cur, cg + 1, sbuf ^ 1);
+                dma_begin(cur, cg + 1, sbuf ^ 1);
+                more = true;
             } else if (it + 1 < count) {
                 nxt = decode(first + (it + 1) * step);
                 setup_dma(nxt);
-                issue_patch(nxt, 0, sbuf ^ 1);
-                issue_filter(nxt, 0, sbuf ^ 1);
+                dma_begin(nxt, 0, sbuf ^ 1);
+                more = true;
             }
-            const char *pb = patch + sbuf * PATCH_BYTES;
+            if (PROBE & 1) more = false;
+            const char *pb = patch + sbuf * PATCH_BYTES + plane_off;
             const char *fb = filt + sbuf * FILT_BYTES + wlane;
 #pragma unroll
-            for (int t = 0; t < T; ++t) {
+            for (int t = 0; t < ((PROBE & 2) ? 0 : T); ++t) {
                 const int ky = t / KS, kx = t % KS;
                 f16x8 xh[2], xl[2], wh[NT], wl[NT];
 #pragma unroll
                 for (int m = 0; m < 2; ++m) {
-                    const int q = qlane + (m + ky) * PW + kx;
-                    const int off = q * 64 + ((hh ^ ((q >> 2) & 3)) << 4);
-                    xh[m] = *(const f16x8 *)(pb + off);
-                    xl[m] = *(const f16x8 *)(pb + (off ^ 32));
+                    xh[m] = *(const f16x8 *)(pb + ((m + ky) * PW + kx) * 16);
+                    xl[m] = *(const f16x8 *)(pb + ((m + ky) * PW + kx + 2 * NPIX) * 16);
                 }
 #pragma unroll
                 for (int n = 0; n < NT; ++n) {
@@ -247,26 +259,61 @@ __global__ __launch_bounds__(512, 2) void conv_s16_kernel(const S16K a) {
                     wl[n] = *(const f16x8 *)(fb + ((t * 4 + 2) * CB + n * 32) * 16);
                 }
 #pragma unroll
-                for (int m = 0; m < 2; ++m)
+                for (int m = 0; m < 2; ++m) {
 #pragma unroll
                     for (int n = 0; n < NT; ++n) {
                         acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[n], xh[m], acc[m][n], 0, 0, 0);
                         acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[n], xh[m], acc[m][n], 0, 0, 0);
                         acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[n], xl[m], acc[m][n], 0, 0, 0);
                     }
+                    // the step's DMA rounds ride in the first taps, so that the last one still has most of
+                    // the multiply phase to land
+                    if (t < NR && more && m == late) dma_round(t);
+                }
+            }
+            if ((PROBE & 2) && more) {
+#pragma unroll
+                for (int u = 0; u < NR; ++u) dma_round(u);
             }
             sbuf ^= 1;
         }
 
-        // ---- epilogue: each lane owns 16 consecutive (packed-order) channels of one pixel per (m, n)
+        // ---- epilogue: each lane owns 16 consecutive (packed-order) channels of one pixel per (m, n).
+        // Everything is computed TIMES ACT_SCALE (a power of two: bit-identical to scaling at the end), which
+        // is the domain the s16 operands live in.
         const int Cq = a.Cout >> 2;
         const int Ho = a.ps ? a.H * 2 : a.H, Wo = a.ps ? a.W * 2 : a.W;
         const int Cfin = a.ps ? Cq : a.Cout;
-        const float inv_scale = 1.f / (ACT_SCALE * WGT_SCALE);
+        const size_t hw = (size_t)Ho * Wo;
+        const float inv_scale = 1.f / WGT_SCALE;  // accumulators carry ACT_SCALE * WGT_SCALE
         bool sat = false;
+        if (PROBE & 4) {  // keep the accumulators alive without touching memory
 #pragma unroll
-        for (int m = 0; m < 2; ++m) {
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int n = 0; n < NT; ++n) keep_alive(acc[m][n]);
+        }
+#pragma unroll
+        for (int m = 0; m < ((PROBE & 4) ? 0 : 2); ++m) {
             const int oy = cur.y0 + r0 + m, ox = cur.x0 + col;
+            // the residual loads of a row go out before its first store (res may alias an output: each element
+            // is read and written by the same lane), so their latency is paid once per row, not per channel tile
+            float rres[NT][16];
+            if (a.res) {
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+                    const int cb = cur.blk * CB + n * 32 + 16 * hh;
+                    if (!(oy < a.H && ox < a.W && cb < a.Cout)) continue;
+                    int cf = cb, dy = 0, dx = 0;
+                    if (a.ps) {
+                        const int sub = cb / Cq;
+                        cf = cb - sub * Cq;
+                        dy = sub >> 1, dx = sub & 1;
+                    }
+                    const size_t pin = a.ps ? ((size_t)(2 * oy + dy) * Wo + 2 * ox + dx) : ((size_t)oy * Wo + ox);
+                    load16x8(a.res, (size_t)cur.img * hw + pin, cur.img, pin, hw, a.res_cs, a.res_fmt, cf, rres[n]);
+                }
+            }
 #pragma unroll
             for (int n = 0; n < NT; ++n) {
                 const int cb = cur.blk * CB + n * 32 + 16 * hh;
@@ -277,16 +324,16 @@ __global__ __launch_bounds__(512, 2) void conv_s16_kernel(const S16K a) {
                     cf = cb - sub * Cq;
                     dy = sub >> 1, dx = sub & 1;
                 }
-                const size_t pixel = a.ps ? ((size_t)(cur.img * Ho + 2 * oy + dy) * Wo + 2 * ox + dx)
-                                          : ((size_t)(cur.img * Ho + oy) * Wo + ox);
-                float v[16], rv[16], rv2[16];
-                if (a.res) load16(a.res, pixel, a.res_cs, a.res_fmt, cf, rv);
-                if (a.res2) load16(a.res2, pixel, a.res2_cs, a.res2_fmt, cf, rv2);
+                const size_t pin = a.ps ? ((size_t)(2 * oy + dy) * Wo + 2 * ox + dx) : ((size_t)oy * Wo + ox);
+                const size_t pixel = (size_t)cur.img * hw + pin;
+                float v[16], rv2[16];
+                const float *rv = rres[n];
+                if (a.res2) load16x8(a.res2, pixel, cur.img, pin, hw, a.res2_cs, a.res2_fmt, cf, rv2);
                 {
                     const f32x4 *bp = (const f32x4 *)(a.bpack + cb);
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        const f32x4 b4 = bp[i];
+                        const f32x4 b4 = bp[i] * ACT_SCALE;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[4 * i + e] = acc[m][n][4 * i + e] * inv_scale + b4[e];
                     }
@@ -296,13 +343,13 @@ __global__ __launch_bounds__(512, 2) void conv_s16_kernel(const S16K a) {
                     for (int i = 0; i < 16; ++i) v[i] = lrelu(v[i], a.out_slope);
                 } else if (a.out_act == 2) {
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) v[i] = fminf(fmaxf(v[i], 0.f), 1.f);
+                    for (int i = 0; i < 16; ++i) v[i] = fminf(fmaxf(v[i], 0.f), ACT_SCALE);
                 }
                 if (a.res) {
                     if (a.res_gate) {
                         const float *gp = a.res_gate + (size_t)cur.img * Cfin + cf;
 #pragma unroll
-                        for (int i = 0; i < 16; ++i) v[i] += rv[i] * gp[i];
+                        for (int i = 0; i < 16; ++i) v[i] = __builtin_fmaf(rv[i], gp[i], v[i]);
                     } else {
 #pragma unroll
                         for (int i = 0; i < 16; ++i) v[i] += rv[i];
@@ -315,21 +362,25 @@ __global__ __launch_bounds__(512, 2) void conv_s16_kernel(const S16K a) {
                 if (a.out) {
                     f32x4 *op = (f32x4 *)(a.out + pixel * a.out_cs + cf);
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) op[i] = (f32x4){v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]};
+                    for (int i = 0; i < 4; ++i)
+                        op[i] = (f32x4){v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]} * (1.f / ACT_SCALE);
                 }
                 if (a.out16) {
                     f16x8 h[2], l[2];
 #pragma unroll
                     for (int i = 0; i < 16; ++i) {
-                        float s = (a.out16_act ? lrelu(v[i], a.out16_slope) : v[i]) * ACT_SCALE;
+                        float s = a.out16_act ? lrelu(v[i], a.out16_slope) : v[i];
                         sat |= !(fabsf(s) <= F16_MAX);
                         s = __builtin_amdgcn_fmed3f(s, -F16_MAX, F16_MAX);
                         const _Float16 hi = (_Float16)s;
                         h[i >> 3][i & 7] = hi;
                         l[i >> 3][i & 7] = (_Float16)(s - (float)hi);
                     }
-                    f16x8 *op = (f16x8 *)(a.out16 + pixel * a.out16_cs * 4 + (size_t)(cf >> 4) * 64);
-                    op[0] = h[0], op[1] = h[1], op[2] = l[0], op[3] = l[1];
+                    char *op = a.out16 + ((((size_t)cur.img * (a.out16_cs >> 4) + (cf >> 4)) * 4) * hw + pin) * 16;
+                    *(f16x8 *)op = h[0];
+                    *(f16x8 *)(op + hw * 16) = h[1];
+                    *(f16x8 *)(op + hw * 32) = l[0];
+                    *(f16x8 *)(op + hw * 48) = l[1];
                 }
             }
         }
@@ -340,14 +391,14 @@ __global__ __launch_bounds__(512, 2) void conv_s16_kernel(const S16K a) {
 
 int g_cus = 0;
 
-template <int NT>
+template <int NT, int PROBE = 0>
 int launch_s16(const S16K &k, hipStream_t st) {
     constexpr int KS = 3, PH = 16 + KS - 1, PW = 32 + KS - 1, CB = 32 * NT;
     constexpr int PATCH_BYTES = ((PH * PW * 4 + 63) / 64) * 1024, FILT_BYTES = KS * KS * 4 * CB * 16;
     constexpr int LDS = 2 * (PATCH_BYTES + FILT_BYTES);
     static int attr = -1;
     if (attr < 0)
-        attr = hipFuncSetAttribute((const void *)conv_s16_kernel<KS, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) ==
+        attr = hipFuncSetAttribute((const void *)conv_s16_kernel<KS, NT, PROBE>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) ==
                        hipSuccess
                    ? 1
                    : 0;
@@ -361,7 +412,7 @@ int launch_s16(const S16K &k, hipStream_t st) {
     const int total = k.nblk * k.N * k.ntx * k.nty;
     int G = total < g_cus ? total : g_cus;
     if (G >= 8) G &= ~7;
-    hipLaunchKernelGGL((conv_s16_kernel<KS, NT>), dim3(G), dim3(512), LDS, st, k);
+    hipLaunchKernelGGL((conv_s16_kernel<KS, NT, PROBE>), dim3(G), dim3(512), LDS, st, k);
     return hipGetLastError() == hipSuccess ? DCVC_OK : DCVC_E_LAUNCH;
 }
 
@@ -369,13 +420,15 @@ inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 inline bool al64(const void *p) { return (((uintptr_t)p) & 63) == 0; }
 
 // ---- fp32 <-> S16 conversion of a strided NHWC tensor (boundary of the format) -----------------
+// one thread per (chunk, pixel), pixels fastest: the s16 side is contiguous, the fp32 side strided
 __global__ void s16_pack_kernel(const float *__restrict__ src, int src_cs, char *__restrict__ out, int out_cs, int64_t npix,
-                                int C, int act, float slope, int *status) {
+                                int64_t hw, int C, int act, float slope, int *status) {
     const int nch = (C + 15) >> 4;
     const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= npix * nch) return;
-    const int64_t pix = gid / nch;
-    const int ch = (int)(gid - pix * nch);
+    const int ch = (int)(gid / npix);
+    const int64_t pix = gid - (int64_t)ch * npix;
+    const int64_t img = pix / hw, pin = pix - img * hw;
     f16x8 h[2], l[2];
     bool sat = false;
 #pragma unroll
@@ -390,23 +443,27 @@ __global__ void s16_pack_kernel(const float *__restrict__ src, int src_cs, char 
         h[i >> 3][i & 7] = hi;
         l[i >> 3][i & 7] = (_Float16)(s - (float)hi);
     }
-    f16x8 *op = (f16x8 *)(out + pix * out_cs * 4 + (size_t)ch * 64);
-    op[0] = h[0], op[1] = h[1], op[2] = l[0], op[3] = l[1];
+    char *op = out + (((img * (out_cs >> 4) + ch) * 4) * hw + pin) * 16;
+    *(f16x8 *)op = h[0];
+    *(f16x8 *)(op + hw * 16) = h[1];
+    *(f16x8 *)(op + hw * 32) = l[0];
+    *(f16x8 *)(op + hw * 48) = l[1];
     if (sat && status) atomicOr(status, DCVC_STATUS_ACT_SATURATED);
 }
 
 __global__ void s16_unpack_kernel(const char *__restrict__ src, int src_cs, float *__restrict__ out, int out_cs, int64_t npix,
-                                  int C) {
+                                  int64_t hw, int C) {
     const int nch = (C + 15) >> 4;
     const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= npix * nch) return;
-    const int64_t pix = gid / nch;
-    const int ch = (int)(gid - pix * nch);
+    const int ch = (int)(gid / npix);
+    const int64_t pix = gid - (int64_t)ch * npix;
+    const int64_t img = pix / hw, pin = pix - img * hw;
     float v[16];
-    load16(src, (size_t)pix, src_cs, DCVC_FMT_S16, ch * 16, v);
+    load16x8(src, (size_t)pix, (int)img, (size_t)pin, (size_t)hw, src_cs, DCVC_FMT_S16, ch * 16, v);
 #pragma unroll
     for (int i = 0; i < 16; ++i)
-        if (ch * 16 + i < C) out[pix * out_cs + ch * 16 + i] = v[i];
+        if (ch * 16 + i < C) out[pix * out_cs + ch * 16 + i] = v[i] * (1.f / ACT_SCALE);
 }
 
 }  // namespace
@@ -465,22 +522,22 @@ extern "C" int dcvc_conv_s16_pack_weights(const float *w, const float *b, int32_
     return status;
 }
 
-extern "C" int dcvc_conv2d_s16(const dcvc_conv_s16_args *a, void *stream) {
+namespace {
+int build_s16k(const dcvc_conv_s16_args *a, S16K &k, int &CB) {
     if (!a || a->nseg < 1 || a->nseg > DCVC_MAX_SEG || !a->wpack || !a->bpack || (!a->out && !a->out16)) return DCVC_E_ARG;
     if (a->ks != 3 || a->Cout <= 0 || (a->Cout & 15) || a->Cout_pad != round_up(a->Cout, 32)) return DCVC_E_ARG;
     if (a->N <= 0 || a->H <= 0 || a->W <= 0) return DCVC_E_ARG;
     const int cfin = a->pixel_shuffle ? a->Cout / 4 : a->Cout;
     if (a->pixel_shuffle && ((a->Cout & 3) || (cfin & 15))) return DCVC_E_ARG;
-    S16K k;
     memset(&k, 0, sizeof(k));
     for (int s = 0; s < a->nseg; ++s) {
         if (!a->seg[s].ptr || !al64(a->seg[s].ptr) || (a->seg[s].C & 15) || a->seg[s].C <= 0 || (a->seg[s].cs & 15) ||
             a->seg[s].cs < a->seg[s].C)
             return DCVC_E_ARG;
-        if ((int64_t)a->H * a->W * a->seg[s].cs * 4 >= (1ll << 32)) return DCVC_E_ARG;  // 32-bit pixel byte offsets
+        if ((int64_t)a->H * a->W * 64 >= (1ll << 32)) return DCVC_E_ARG;  // 32-bit in-plane byte offsets
         k.seg_ptr[s] = (const char *)a->seg[s].ptr;
         k.seg_chunks[s] = a->seg[s].C / KC;
-        k.seg_cs[s] = a->seg[s].cs;
+        k.seg_planes[s] = a->seg[s].cs / KC;
         k.nchunks += k.seg_chunks[s];
     }
     auto ok_f32 = [](const void *p, int cs) { return p == nullptr || ((((uintptr_t)p) & 15) == 0 && (cs & 3) == 0); };
@@ -494,7 +551,7 @@ extern "C" int dcvc_conv2d_s16(const dcvc_conv_s16_args *a, void *stream) {
     k.wpack = (const char *)a->wpack;
     k.bpack = a->bpack;
     k.Cout = a->Cout;
-    const int CB = (a->Cout_pad % 64 == 0) ? 64 : 32;
+    CB = (a->Cout_pad % 64 == 0) ? 64 : 32;
     k.nblk = a->Cout_pad / CB;
     k.out = a->out, k.out_cs = a->out_cs, k.out_act = a->out_act, k.out_slope = a->out_slope;
     k.out16 = (char *)a->out16, k.out16_cs = a->out16_cs, k.out16_act = a->out16_act, k.out16_slope = a->out16_slope;
@@ -504,25 +561,36 @@ extern "C" int dcvc_conv2d_s16(const dcvc_conv_s16_args *a, void *stream) {
     k.res2 = (const char *)a->res2, k.res2_cs = a->res2_cs, k.res2_fmt = a->res2_fmt;
     k.status = a->status;
     k.ntx = (a->W + 31) / 32, k.nty = (a->H + 15) / 16;
+    return DCVC_OK;
+}
+}  // namespace
+
+extern "C" int dcvc_conv2d_s16(const dcvc_conv_s16_args *a, void *stream) {
+    S16K k;
+    int CB = 0;
+    const int rc = build_s16k(a, k, CB);
+    if (rc != DCVC_OK) return rc;
     return CB == 64 ? launch_s16<2>(k, (hipStream_t)stream) : launch_s16<1>(k, (hipStream_t)stream);
 }
 
-extern "C" int dcvc_s16_pack(const float *src, int32_t src_cs, void *out, int32_t out_cs, int64_t npix, int32_t C,
+extern "C" int dcvc_s16_pack(const float *src, int32_t src_cs, void *out, int32_t out_cs, int32_t N, int64_t hw, int32_t C,
                              int32_t act, float slope, int32_t *status, void *stream) {
-    if (!src || !out || C <= 0 || npix < 0 || (out_cs & 15) || out_cs < round_up(C, 16) || !al64(out)) return DCVC_E_ARG;
+    if (!src || !out || C <= 0 || N < 0 || hw < 0 || (out_cs & 15) || out_cs < round_up(C, 16) || !al64(out)) return DCVC_E_ARG;
+    const int64_t npix = (int64_t)N * hw;
     if (npix == 0) return DCVC_OK;
     const int64_t total = npix * ((C + 15) / 16);
     hipLaunchKernelGGL(s16_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, src_cs,
-                       (char *)out, out_cs, npix, C, act, slope, status);
+                       (char *)out, out_cs, npix, hw, C, act, slope, status);
     return hipGetLastError() == hipSuccess ? DCVC_OK : DCVC_E_LAUNCH;
 }
 
-extern "C" int dcvc_s16_unpack(const void *src, int32_t src_cs, float *out, int32_t out_cs, int64_t npix, int32_t C,
+extern "C" int dcvc_s16_unpack(const void *src, int32_t src_cs, float *out, int32_t out_cs, int32_t N, int64_t hw, int32_t C,
                                void *stream) {
-    if (!src || !out || C <= 0 || npix < 0 || (src_cs & 15) || src_cs < round_up(C, 16) || !al64(src)) return DCVC_E_ARG;
+    if (!src || !out || C <= 0 || N < 0 || hw < 0 || (src_cs & 15) || src_cs < round_up(C, 16) || !al64(src)) return DCVC_E_ARG;
+    const int64_t npix = (int64_t)N * hw;
     if (npix == 0) return DCVC_OK;
     const int64_t total = npix * ((C + 15) / 16);
     hipLaunchKernelGGL(s16_unpack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       (const char *)src, src_cs, out, out_cs, npix, C);
+                       (const char *)src, src_cs, out, out_cs, npix, hw, C);
     return hipGetLastError() == hipSuccess ? DCVC_OK : DCVC_E_LAUNCH;
 }

@@ -59,9 +59,10 @@ class View:
         return None
 
     def slice(self, c0: int, c: int) -> "View":
-        # 16 channels of an s16 buffer are 64 bytes: the byte offset of a chunk-aligned slice is 4 * c0 there too
+        # an s16 buffer is planar in 16-channel chunks: a slice is a run of planes
         assert self.fmt == "f32" or (c0 % 16 == 0 and c % 16 == 0)
-        v = View(self.base, c, 0, geom=(self.N, self.H, self.W, self.cs, self.ptr + 4 * c0), fmt=self.fmt, act=self.act)
+        off = 4 * c0 if self.fmt == "f32" else 4 * c0 * self.H * self.W
+        v = View(self.base, c, 0, geom=(self.N, self.H, self.W, self.cs, self.ptr + off), fmt=self.fmt, act=self.act)
         v.coff = self.coff + c0
         if self.twin is not None and c0 % 16 == 0 and c % 16 == 0:
             v.twin = self.twin.slice(c0, c)
@@ -91,7 +92,7 @@ class View:
 
 class PackedConv:
     __slots__ = ("w", "b", "ks", "Cout", "Cout_pad", "seg_C", "ps", "version", "precision", "weight", "bias",
-                 "cin_slice", "key")
+                 "cin_slice", "key", "s16")
 
 
 class Engine:
@@ -165,9 +166,7 @@ class Engine:
         if src.twin is None or src.twin.act != act:
             src.twin = View(self._twin_tensor(src), src.C, fmt="s16", act=act)
         t = src.twin
-        lib.check(self.L.dcvc_s16_pack(src.ptr, src.cs, t.ptr, t.cs, src.N * src.HW, src.C, int(act is not None),
-                                       float(act or 0.0), self.status_word().data_ptr(), self.stream()), "s16_pack")
-        self.calls += 1
+        self.s16_pack_into(src, t)
         return t
 
     def _twin_tensor(self, src: View) -> torch.Tensor:
@@ -180,7 +179,7 @@ class Engine:
         return t
 
     def s16_unpack(self, src: View, out: View) -> View:
-        lib.check(self.L.dcvc_s16_unpack(src.ptr, src.cs, out.ptr, out.cs, src.N * src.HW, src.C, self.stream()), "s16_unpack")
+        lib.check(self.L.dcvc_s16_unpack(src.ptr, src.cs, out.ptr, out.cs, src.N, src.HW, src.C, self.stream()), "s16_unpack")
         self.calls += 1
         return out
 
@@ -323,7 +322,7 @@ class Engine:
 
     def pack_s16(self, pk: PackedConv) -> PackedConv:
         """The same layer packed for dcvc_conv2d_s16 (cached beside the fp16x3 packing)."""
-        q = getattr(pk, "s16", None)
+        q = getattr(pk, "s16", None)  # (slot is unset until the first call)
         if q is not None and q.version == pk.version:
             return q
         w = pk.weight.detach().float().cpu()
@@ -369,7 +368,7 @@ class Engine:
         return out
 
     def s16_pack_into(self, src: View, t: View):
-        lib.check(self.L.dcvc_s16_pack(src.ptr, src.cs, t.ptr, t.cs, src.N * src.HW, src.C, int(t.act is not None),
+        lib.check(self.L.dcvc_s16_pack(src.ptr, src.cs, t.ptr, t.cs, src.N, src.HW, src.C, int(t.act is not None),
                                        float(t.act or 0.0), self.status_word().data_ptr(), self.stream()), "s16_pack")
         self.calls += 1
 

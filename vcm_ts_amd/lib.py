@@ -140,8 +140,8 @@ _SIGS = {
     "dcvc_conv_pack_weights": [vp, vp, i32, i32, i32, vp, i32, i32, vp, vp],
     "dcvc_conv2d_s16": [C.POINTER(ConvS16Args), vp],
     "dcvc_conv_s16_pack_weights": [vp, vp, i32, i32, i32, vp, i32, vp, vp],
-    "dcvc_s16_pack": [vp, i32, vp, i32, i64, i32, i32, f32, vp, vp],
-    "dcvc_s16_unpack": [vp, i32, vp, i32, i64, i32, vp],
+    "dcvc_s16_pack": [vp, i32, vp, i32, i32, i64, i32, i32, f32, vp, vp],
+    "dcvc_s16_unpack": [vp, i32, vp, i32, i32, i64, i32, vp],
     "dcvc_warp": [vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, vp],
     "dcvc_up2": [vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, f32, vp],
     "dcvc_down2": [vp, i32, vp, i32, i32, i32, i32, i32, f32, i32, vp],
