@@ -97,6 +97,9 @@ typedef struct {
     const float *res2;    /* optional second residual, added last: out = res2 + (act(conv) + res) */
     int32_t res2_cs;
     int32_t precision;    /* DCVC_PREC_* ; must match the packing of wpack */
+    int32_t *status;      /* optional device word: OR-ed with DCVC_STATUS_ACT_SATURATED when an OUTPUT of this launch
+                             has |v| > 8188, the magnitude a DCVC_PREC_FP16X3 consumer would clamp on load.  NULL: no
+                             check (and no cost).  Weights are range-checked at pack time (DCVC_E_RANGE). */
 } dcvc_conv_args;
 
 /* Number of floats dcvc_conv_pack_weights writes to wpack for this geometry, and the padded

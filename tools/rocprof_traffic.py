@@ -2,8 +2,12 @@
 WRITE_SIZE in separate runs, as MI355X_MICROARCH.md prescribes).  FETCH_SIZE is doubled: on
 gfx950 it reports half the bytes of wide (16 B/lane) coalesced streaming reads; WRITE_SIZE is
 exact for 16 B/lane stores.  Both counters are in KB.
-    python tools/rocprof_traffic.py fetch.db write.db 'conv_mfma<3, 1, 2, 2, true>' fp16x3"""
+    python tools/rocprof_traffic.py fetch.db write.db 'conv_mfma<3, 1, 2, 2, true>' fp16x3 [height width]
+The JSON records the picture size and a hash of the kernel sources: bench.py quotes the figure only for a run
+of the same size on the same kernels."""
 import json, os, sqlite3, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 
 def avg(path, counter, pattern):
     c = sqlite3.connect(path)
@@ -11,10 +15,13 @@ def avg(path, counter, pattern):
                   (counter, f"%{pattern}%")).fetchone()
     return r
 
-def main(fdb, wdb, pattern, precision):
+def main(fdb, wdb, pattern, precision, height=1080, width=1920):
+    from bench import kernel_source_hash
+
     nf, f, df = avg(fdb, "FETCH_SIZE", pattern)
     nw, w, dw = avg(wdb, "WRITE_SIZE", pattern)
-    out = {"kernel": pattern, "launches_sampled": nf, "fetch_size_kb_raw": f, "fetch_bytes_corrected_x2": 2 * f * 1024,
+    out = {"kernel": pattern, "height": int(height), "width": int(width), "kernel_source_sha16": kernel_source_hash(),
+           "launches_sampled": nf, "fetch_size_kb_raw": f, "fetch_bytes_corrected_x2": 2 * f * 1024,
            "write_bytes": w * 1024, "bytes_per_launch": round(2 * f * 1024 + w * 1024), "avg_duration_us_fetch_pass": df / 1e3,
            "avg_duration_us_write_pass": dw / 1e3, "note": "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B requests at 64 B)"}
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -22,4 +29,4 @@ def main(fdb, wdb, pattern, precision):
     print(json.dumps(out, indent=1))
 
 if __name__ == "__main__":
-    main(*sys.argv[1:5])
+    main(*sys.argv[1:7])

@@ -72,21 +72,13 @@ struct ConvK {
     const float *res2;
     int res2_cs;
     int vec_epi;  // 1: every output / residual row is 16-byte addressable in groups of 4 channels
+    int *status;  // optional: flag outputs a split-fp16 consumer would clamp
 };
+
+constexpr float ACT_LIMIT = 65504.f / 8.f;  // F16_MAX / ACT_SCALE
 
 __device__ __forceinline__ float act(float v, float slope) { return v > 0.f ? v : v * slope; }
 
-#ifdef PROBE_STAMP
-// developer probe: per-workgroup s_memtime stamps of the main-loop phases (tools/conv_stamps.py)
-__device__ unsigned long long *g_stamps = nullptr;
-#define STAMP(k)                                                                              \
-    do {                                                                                      \
-        if (tid == 0 && g_stamps && stamp_i < 62) g_stamps[(size_t)(blockIdx.x + gridDim.x * blockIdx.y) * 64 + 2 + stamp_i++] = \
-            __builtin_amdgcn_s_memtime();                                                     \
-    } while (0)
-#else
-#define STAMP(k)
-#endif
 
 __device__ __forceinline__ void split_f16(float v, _Float16 &hi, _Float16 &lo) {
     v = fminf(fmaxf(v * ACT_SCALE, -F16_MAX), F16_MAX);
@@ -94,21 +86,12 @@ __device__ __forceinline__ void split_f16(float v, _Float16 &hi, _Float16 &lo) {
     lo = (_Float16)(v - (float)hi);
 }
 
-#ifdef PROBE_TPS3
-#define CLASSIC_WAVES_PER_SIMD 3
-#else
-#define CLASSIC_WAVES_PER_SIMD 2
-#endif
 template <int KS, int S, int RPW, int NT, bool SPLIT>
-__global__ __launch_bounds__(256, CLASSIC_WAVES_PER_SIMD) void conv_mfma(const ConvK a) {
+__global__ __launch_bounds__(256, 2) void conv_mfma(const ConvK a) {
     constexpr int BH = 4 * RPW, BW = 32, BN = 32 * NT;
     constexpr int PH = (BH - 1) * S + KS, PW = (BW - 1) * S + KS, PAD = KS / 2;
     constexpr int T = KS * KS;
-#ifdef PROBE_TPS3
-    constexpr int TPS = KS;
-#else
     constexpr int TPS = (KS == 3 && S == 1) ? 9 : KS;  // taps staged in LDS at a time
-#endif
     constexpr int NST = T / TPS;
     constexpr int EPI_LD = BN + 4;  // floats per pixel row of the epilogue's transpose tile
     constexpr int LDS_MAIN = PH * PW * LDK + TPS * 4 * BN * 4, LDS_EPI = 4 * 32 * EPI_LD;
@@ -228,35 +211,20 @@ __global__ __launch_bounds__(256, CLASSIC_WAVES_PER_SIMD) void conv_mfma(const C
     };
 
     Cursor cur = {0, 0, 0, 0};
-#ifdef PROBE_STAMP
-    int stamp_i = 0;
-    if (tid == 0 && g_stamps) g_stamps[(size_t)(blockIdx.x + gridDim.x * blockIdx.y) * 64] = __builtin_amdgcn_s_memrealtime();
-#endif
-    STAMP(0);
     load_patch(cur);
     load_w(cur);
     while (cur.s < a.nseg) {
         __syncthreads();  // every wave is done reading the previous step's LDS
-        STAMP(1);
-#ifndef PROBE_NO_STORE
         if (cur.st == 0) store_patch(cur);
         store_w();
-#endif
-        STAMP(2);
         __syncthreads();
-        STAMP(3);
         Cursor nxt = cur;
         advance(nxt);
-#ifndef PROBE_NO_LOAD
         if (nxt.s < a.nseg) {
             if (nxt.st == 0) load_patch(nxt);
             load_w(nxt);
         }
-#endif
         const int a_st = (TPS == T) ? 0 : cur.st * PW * LDK;  // staged by filter row
-#ifdef PROBE_NO_MFMA
-        if (a.Hin < 0)
-#endif
 #pragma unroll
         for (int tt = 0; tt < TPS; ++tt) {
             const int ky = (TPS == T) ? tt / KS : 0, kx = (TPS == T) ? tt % KS : tt;
@@ -303,25 +271,16 @@ __global__ __launch_bounds__(256, CLASSIC_WAVES_PER_SIMD) void conv_mfma(const C
                     }
             }
         }
-        STAMP(4);
         cur = nxt;
     }
 
-#ifdef PROBE_NO_EPILOGUE
-    if (a.Hin > 0 && acc[0][0][0] != 12345.678f) {
-        STAMP(5);
-#ifdef PROBE_STAMP
-        if (tid == 0 && g_stamps) g_stamps[(size_t)(blockIdx.x + gridDim.x * blockIdx.y) * 64 + 1] = __builtin_amdgcn_s_memrealtime();
-#endif
-        return;
-    }
-#endif
     // ---- epilogue: bias, activation, (gated) residual(s), NHWC or pixel-shuffled store.
     const int col = lane & 31, hh = lane >> 5;
     const int Cq = a.Cout >> 2;
     const int Cfin = a.ps ? Cq : a.Cout;
     const int Ho = a.ps ? a.Hout * 2 : a.Hout, Wo = a.ps ? a.Wout * 2 : a.Wout;
     const float inv_scale = SPLIT ? 1.f / (ACT_SCALE * WGT_SCALE) : 1.f;
+    bool sat = false;
     if (a.vec_epi) {
         // Vector path: the MFMA leaves a channel per lane and pixels in registers; a per-wave
         // transpose through LDS turns that into 4 consecutive channels per lane, so every
@@ -397,14 +356,13 @@ __global__ __launch_bounds__(256, CLASSIC_WAVES_PER_SIMD) void conv_mfma(const C
                     }
                 }
                 if (a.res2) v = rv2[m][it] + v;
+                if (a.status && ok[m][it])
+                    sat |= !(fabsf(v[0]) <= ACT_LIMIT && fabsf(v[1]) <= ACT_LIMIT && fabsf(v[2]) <= ACT_LIMIT && fabsf(v[3]) <= ACT_LIMIT);
                 if (ok[m][it]) *(f32x4 *)&a.out[pix[m][it] * a.out_cs + cf] = v;
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // reads done before the tile is rewritten
         }
-        STAMP(5);
-#ifdef PROBE_STAMP
-        if (tid == 0 && g_stamps) g_stamps[(size_t)(blockIdx.x + gridDim.x * blockIdx.y) * 64 + 1] = __builtin_amdgcn_s_memrealtime();
-#endif
+        if (sat) atomicOr(a.status, DCVC_STATUS_ACT_SATURATED);
         return;
     }
     // Scalar path (odd channel counts / unaligned slices: 2- and 3-channel outputs).
@@ -445,10 +403,12 @@ __global__ __launch_bounds__(256, CLASSIC_WAVES_PER_SIMD) void conv_mfma(const C
                                         : ((size_t)(img * Ho + oy) * Wo + ox);
                 if (a.res) v = a.res_gate ? __builtin_fmaf(rv[r], gate, v) : v + rv[r];
                 if (a.res2) v = rv2[r] + v;
+                if (a.status && !(fabsf(v) <= ACT_LIMIT)) sat = true;
                 a.out[pix * a.out_cs + cf] = v;
             }
         }
     }
+    if (sat) atomicOr(a.status, DCVC_STATUS_ACT_SATURATED);
 }
 
 
@@ -466,10 +426,6 @@ int launch(const ConvK &k, int N, hipStream_t st, int precision) {
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
 }  // namespace
-
-#ifdef PROBE_STAMP
-extern "C" int dcvc_probe_set_stamps(void *p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), &p, sizeof(p)); }
-#endif
 
 extern "C" int64_t dcvc_conv_pack_size(int32_t Cout, int32_t ks, int32_t nseg, const int32_t *seg_C, int32_t *cout_pad) {
     if (Cout <= 0 || nseg <= 0 || nseg > DCVC_MAX_SEG || (ks != 1 && ks != 3 && ks != 7)) return DCVC_E_ARG;
@@ -568,6 +524,7 @@ extern "C" int dcvc_conv2d(const dcvc_conv_args *a, void *stream) {
     k.res_gate = a->res_gate;
     k.res2 = a->res2;
     k.res2_cs = a->res2_cs;
+    k.status = a->status;
     {
         const int cfin = a->pixel_shuffle ? a->Cout / 4 : a->Cout;
         auto al = [](const void *p, int cs) { return p == nullptr || ((((uintptr_t)p) & 15) == 0 && (cs & 3) == 0); };

@@ -115,6 +115,10 @@ class Engine:
         self._edges = {}     # distribution -> device (256,) fp32 bin edges of build_indexes
         self._status = None  # device status word of the split-fp16 kernels (saturation flag)
         self.use_s16 = os.environ.get("DCVC_S16", "1") != "0"
+        # fp16x3 mode clamps |activation| > 8188 on load; with range_check on, every convolution launch also
+        # flags outputs beyond that magnitude in the status word (check_status() raises).  Off by default: it
+        # costs VALU work in the epilogue; bench.py and the tests turn it on for a checked pass.
+        self.range_check = os.environ.get("DCVC_RANGE_CHECK", "0") == "1"
 
     # ------------------------------------------------------------------ memory
     def stream(self):
@@ -153,13 +157,20 @@ class Engine:
             self._status = torch.zeros(1, dtype=torch.int32, device=self.device)
         return self._status
 
+    def read_status(self) -> int:
+        """Status word of the split-fp16 kernels since the last read (synchronises); 0 = nothing clamped."""
+        if self._status is None:
+            return 0
+        v = int(self._status.item())
+        if v:
+            self._status.zero_()
+        return v
+
     def check_status(self):
-        """Raise if a split-fp16 kernel clamped an activation since the last call (synchronises)."""
-        if self._status is not None:
-            v = int(self._status.item())
-            if v:
-                self._status.zero_()
-                raise lib.KernelError(f"split-fp16 activation range exceeded (status {v}): |x| > 8188; use precision='fp32'")
+        """Raise if a split-fp16 kernel clamped (or would clamp) an activation since the last call."""
+        v = self.read_status()
+        if v:
+            raise lib.KernelError(f"split-fp16 activation range exceeded (status {v}): |x| > 8188; use precision='fp32'")
 
     def s16_pack(self, src: View, act=None) -> View:
         """fp32 view -> its s16 twin by a conversion pass (for tensors no fast-path convolution produced)."""
@@ -456,6 +467,8 @@ class Engine:
         if res2 is not None:
             assert (res2.N, res2.H, res2.W, res2.C) == (out.N, out.H, out.W, out.C)
             a.res2, a.res2_cs = res2.ptr, res2.cs
+        if self.range_check and self.precision == "fp16x3":
+            a.status = self.status_word().data_ptr()
         self._launch_conv(lambda: lib.check(self.L.dcvc_conv2d(C.byref(a), self.stream()), "conv2d"), pk, s0, Ho, Wo, stride,
                           res, res2)
         self.calls += 1

@@ -69,7 +69,7 @@ class ConvArgs(C.Structure):
         ("ks", C.c_int32), ("stride", C.c_int32), ("Cout", C.c_int32), ("Cout_pad", C.c_int32),
         ("out", C.c_void_p), ("out_cs", C.c_int32), ("out_act", C.c_int32), ("out_slope", C.c_float),
         ("pixel_shuffle", C.c_int32), ("res", C.c_void_p), ("res_cs", C.c_int32), ("res_gate", C.c_void_p),
-        ("res2", C.c_void_p), ("res2_cs", C.c_int32), ("precision", C.c_int32),
+        ("res2", C.c_void_p), ("res2_cs", C.c_int32), ("precision", C.c_int32), ("status", C.c_void_p),
     ]
 
 
