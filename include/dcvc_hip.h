@@ -100,7 +100,17 @@ typedef struct {
     int32_t *status;      /* optional device word: OR-ed with DCVC_STATUS_ACT_SATURATED when an OUTPUT of this launch
                              has |v| > 8188, the magnitude a DCVC_PREC_FP16X3 consumer would clamp on load.  NULL: no
                              check (and no cost).  Weights are range-checked at pack time (DCVC_E_RANGE). */
+    float *chan_partial;  /* optional (N, parts, Cout_pad) floats, parts = dcvc_conv_chan_partial_parts(): every
+                             workgroup writes the per-channel sums of the outputs it stored, so that SELayer's global
+                             average pool (video_net.py:149-162) costs no second pass over the tensor; finish with
+                             dcvc_channel_mean_finish.  Not with pixel_shuffle; needs the 16-byte aligned epilogue. */
 } dcvc_conv_args;
+
+/* number of partial rows per image dcvc_conv2d writes to chan_partial for this output size */
+int32_t dcvc_conv_chan_partial_parts(int32_t ks, int32_t stride, int32_t Hout, int32_t Wout);
+/* mean(n, c) = sum over the partial rows (fixed order) / HW */
+int dcvc_channel_mean_finish(const float *chan_partial, int32_t parts, int32_t row_stride, float *mean, int32_t N,
+                             int32_t C, int32_t HW, void *stream);
 
 /* Number of floats dcvc_conv_pack_weights writes to wpack for this geometry, and the padded
  * output-channel count (bias length) through *cout_pad.  seg_C: channels per segment. */

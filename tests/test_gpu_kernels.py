@@ -271,12 +271,18 @@ def test_warp_and_resamplers_match_reference_fixtures(eng):
     np.testing.assert_array_equal(eng.to_nchw(mp).cpu().numpy(), F.max_pool2d(x, 2).numpy())
 
 
-def test_warp_vector_path_and_border(eng):
-    g = torch.Generator().manual_seed(1)
-    im = torch.randn(1, 64, 24, 40, generator=g)
-    fl = torch.randn(1, 2, 24, 40, generator=g) * 30  # mostly out of the picture -> border clamp
+@pytest.mark.parametrize("C,N,H,W", [(64, 1, 24, 40), (8, 2, 9, 31), (16, 1, 17, 23), (32, 2, 12, 20), (128, 1, 10, 14),
+                                     (24, 1, 11, 13), (64, 1, 7, 5)])
+def test_warp_vector_path_and_border(eng, C, N, H, W):
+    """Vector paths of the warp: the wave-shuffle kernel (one lane per pixel computes the tap, ds_swizzle
+    broadcasts it to the pixel's 2 / 4 / 8 / 16 / 32 channel lanes), the every-lane kernel for other channel
+    counts (24), pictures whose pixel count is not a multiple of the lanes per workgroup, two images."""
+    g = torch.Generator().manual_seed(C + H)
+    im = torch.randn(N, C, H, W, generator=g)
+    fl = torch.randn(N, 2, H, W, generator=g) * 30  # mostly out of the picture -> border clamp
+    fl[:, :, : H // 2] *= 0.05                       # and sub-pixel motion in the upper half
     want = R.warp(im, fl)
-    out = eng.warp(to_view(eng, "wv/im", im), to_view(eng, "wv/fl", fl), eng.buf("wv/out", 1, 24, 40, 64))
+    out = eng.warp(to_view(eng, "wv/im", im), to_view(eng, "wv/fl", fl), eng.buf("wv/out", N, H, W, C))
     assert rel_err(eng.to_nchw(out), want) < 3e-6
 
 
@@ -298,6 +304,34 @@ def test_se_gate(eng):
     want = torch.sigmoid(F.linear(F.relu(F.linear(t.mean(dim=(-1, -2)), w1)), w2))
     gate = eng.se_gate("se/t", to_view(eng, "se/in", t), w1.cuda(), w2.cuda())
     torch.testing.assert_close(gate.cpu().reshape(2, 32), want, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("cout,H,W,stride", [(32, 37, 70, 1), (64, 48, 96, 1), (128, 9, 33, 1), (64, 40, 72, 2)])
+def test_fused_se_squeeze_matches_mean_of_the_output(eng, eng_split, cout, H, W, stride):
+    """SELayer's global average pool (video_net.py:149-162) computed by the producing convolution's epilogue
+    (dcvc_conv_args.chan_partial + dcvc_channel_mean_finish): equals the mean of the tensor the launch stored,
+    and the gate built from it equals the separate two-pass reduction's; ragged tiles, two images, both modes."""
+    g = torch.Generator().manual_seed(cout + H)
+    N, cin = 2, 64
+    x = torch.randn(N, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(cin * 9)
+    b = torch.randn(cout, generator=g)
+    w1, w2 = torch.randn(max(cout // 16, 1), cout, generator=g), torch.randn(cout, max(cout // 16, 1), generator=g)
+    for e in (eng, eng_split):
+        pk = e.pack(("sq", cout, H, stride), torch.nn.Parameter(w.cuda()), torch.nn.Parameter(b.cuda()), (cin,), False)
+        xin = to_view(e, "sq/in", x)
+        Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+        out = e.buf("sq/out", N, Ho, Wo, cout)
+        buf, parts = e.chan_partial_buf("sq", pk, out, stride)
+        buf.fill_(float("nan"))
+        e.conv(pk, [xin], out, stride=stride, chan_partial=buf)
+        got_out = e.to_nchw(out).cpu()
+        gate_fused = e.se_gate("sq/f", out, w1.cuda(), w2.cuda(), partial=(buf, parts, pk.Cout_pad)).clone()
+        mean_fused = e.fbuf("sq/f.mean", N * cout).clone()
+        torch.testing.assert_close(mean_fused.cpu().reshape(N, cout), got_out.double().mean(dim=(-1, -2)).float(), rtol=2e-6,
+                                   atol=2e-6)
+        gate_sep = e.se_gate("sq/s", out, w1.cuda(), w2.cuda())
+        torch.testing.assert_close(gate_fused, gate_sep, rtol=1e-5, atol=1e-6)
 
 
 def test_build_indexes_bit_exact_against_reference_planes(eng):

@@ -73,6 +73,7 @@ struct ConvK {
     int res2_cs;
     int vec_epi;  // 1: every output / residual row is 16-byte addressable in groups of 4 channels
     int *status;  // optional: flag outputs a split-fp16 consumer would clamp
+    float *chan_partial;  // optional: per-workgroup channel sums of the stored output (SE layer)
 };
 
 constexpr float ACT_LIMIT = 65504.f / 8.f;  // F16_MAX / ACT_SCALE
@@ -94,8 +95,9 @@ __global__ __launch_bounds__(256, 2) void conv_mfma(const ConvK a) {
     constexpr int TPS = (KS == 3 && S == 1) ? 9 : KS;  // taps staged in LDS at a time
     constexpr int NST = T / TPS;
     constexpr int EPI_LD = BN + 4;  // floats per pixel row of the epilogue's transpose tile
-    constexpr int LDS_MAIN = PH * PW * LDK + TPS * 4 * BN * 4, LDS_EPI = 4 * 32 * EPI_LD;
-    __shared__ __attribute__((aligned(16))) float lds[LDS_MAIN > LDS_EPI ? LDS_MAIN : LDS_EPI];
+    // epilogue: transpose tiles of the four waves, then 4 x BN floats for the fused channel sums
+    constexpr int LDS_MAIN = PH * PW * LDK + TPS * 4 * BN * 4, LDS_EPI = 4 * 32 * EPI_LD, LDS_RED = 4 * BN;
+    __shared__ __attribute__((aligned(16))) float lds[LDS_MAIN > LDS_EPI + LDS_RED ? LDS_MAIN : LDS_EPI + LDS_RED];
     float *patch = lds;
     float *wl = lds + PH * PW * LDK;
 
@@ -310,6 +312,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma(const ConvK a) {
         size_t pix[RPW][NIT];
         bool ok[RPW][NIT];
         f32x4 rv[RPW][NIT], rv2[RPW][NIT];
+        f32x4 csum = {0.f, 0.f, 0.f, 0.f};  // this lane's 4 channels summed over its pixels (SE squeeze)
 #pragma unroll
         for (int m = 0; m < RPW; ++m) {
             const int oy = y0 + wave * RPW + m;
@@ -356,6 +359,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma(const ConvK a) {
                     }
                 }
                 if (a.res2) v = rv2[m][it] + v;
+                if (a.chan_partial && ok[m][it]) csum += v;
                 if (a.status && ok[m][it])
                     sat |= !(fabsf(v[0]) <= ACT_LIMIT && fabsf(v[1]) <= ACT_LIMIT && fabsf(v[2]) <= ACT_LIMIT && fabsf(v[3]) <= ACT_LIMIT);
                 if (ok[m][it]) *(f32x4 *)&a.out[pix[m][it] * a.out_cs + cf] = v;
@@ -363,6 +367,24 @@ __global__ __launch_bounds__(256, 2) void conv_mfma(const ConvK a) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // reads done before the tile is rewritten
         }
         if (sat) atomicOr(a.status, DCVC_STATUS_ACT_SATURATED);
+        if (a.chan_partial) {
+            // SELayer's AdaptiveAvgPool (video_net.py:149-162) rides on the producing convolution: lanes with the
+            // same channel quad are LPP apart -> butterfly inside the wave, the four waves through LDS, one
+            // partial row per workgroup; dcvc_channel_mean_finish adds the rows in a fixed order (no atomics:
+            // encoder and decoder derive bit-identical gates)
+#pragma unroll
+            for (int off = LPP; off < 64; off <<= 1)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) csum[e] += __shfl_xor(csum[e], off);
+            float *red = lds + LDS_EPI;
+            if (lane < LPP) *(f32x4 *)&red[wave * BN + c4] = csum;
+            __syncthreads();
+            if (tid < BN && n0 + tid < a.Cout_pad) {
+                const float s = ((red[tid] + red[BN + tid]) + red[2 * BN + tid]) + red[3 * BN + tid];
+                const size_t part = (size_t)img * (gridDim.y * (gridDim.x / nbn)) + (size_t)blockIdx.y * (gridDim.x / nbn) + tx;
+                a.chan_partial[part * a.Cout_pad + n0 + tid] = s;
+            }
+        }
         return;
     }
     // Scalar path (odd channel counts / unaligned slices: 2- and 3-channel outputs).
@@ -487,6 +509,15 @@ extern "C" int dcvc_conv_pack_weights(const float *w, const float *b, int32_t Co
     return DCVC_OK;
 }
 
+// rows of a workgroup's output tile per (kernel size, stride): 4 * RPW of the instantiations below
+static int tile_rows(int ks, int stride) { return stride == 2 ? 4 : 8; }
+
+extern "C" int32_t dcvc_conv_chan_partial_parts(int32_t ks, int32_t stride, int32_t Hout, int32_t Wout) {
+    if (Hout <= 0 || Wout <= 0 || (stride != 1 && stride != 2)) return DCVC_E_ARG;
+    const int bh = tile_rows(ks, stride);
+    return ((Wout + 31) / 32) * ((Hout + bh - 1) / bh);
+}
+
 extern "C" int dcvc_conv2d(const dcvc_conv_args *a, void *stream) {
     if (!a || a->nseg < 1 || a->nseg > DCVC_MAX_SEG || !a->out || !a->wpack || !a->bpack) return DCVC_E_ARG;
     if (a->stride != 1 && a->stride != 2) return DCVC_E_ARG;
@@ -525,12 +556,14 @@ extern "C" int dcvc_conv2d(const dcvc_conv_args *a, void *stream) {
     k.res2 = a->res2;
     k.res2_cs = a->res2_cs;
     k.status = a->status;
+    k.chan_partial = a->chan_partial;
     {
         const int cfin = a->pixel_shuffle ? a->Cout / 4 : a->Cout;
         auto al = [](const void *p, int cs) { return p == nullptr || ((((uintptr_t)p) & 15) == 0 && (cs & 3) == 0); };
         k.vec_epi = (cfin % 4 == 0) && al(a->out, a->out_cs) && al(a->res, a->res_cs) && al(a->res2, a->res2_cs) &&
                     (a->res_gate == nullptr || (((uintptr_t)a->res_gate) & 15) == 0);
     }
+    if (a->chan_partial && (!k.vec_epi || a->pixel_shuffle)) return DCVC_E_ARG;
     hipStream_t st = (hipStream_t)stream;
     const bool wide = (a->Cout_pad % 64) == 0;
     const int key = a->ks * 10 + a->stride;

@@ -87,6 +87,24 @@ __global__ void channel_finish(const float *__restrict__ scratch, float *__restr
     }
 }
 
+// the same finish over the partial rows a convolution's epilogue wrote (dcvc_conv_args.chan_partial)
+__global__ void channel_finish_rows(const float *__restrict__ part, int parts, int stride, float *__restrict__ mean,
+                                    int HW, int C) {
+    __shared__ float sm[256];
+    const int n = blockIdx.x, t = threadIdx.x;
+    const int c = blockIdx.y * 16 + (t & 15), lane16 = t >> 4;
+    float s = 0.f;
+    if (c < C)
+        for (int b = lane16; b < parts; b += 16) s += part[((size_t)n * parts + b) * stride + c];
+    sm[t] = s;
+    __syncthreads();
+    if (t < 16 && c < C) {
+        float r = 0.f;
+        for (int k = 0; k < 16; ++k) r += sm[k * 16 + t];
+        mean[(size_t)n * C + c] = r / (float)HW;
+    }
+}
+
 __global__ void se_gate_kernel(const float *__restrict__ mean, const float *__restrict__ w1,
                                const float *__restrict__ w2, float *__restrict__ gate, int C, int Cr) {
     __shared__ float hid[64];
@@ -329,6 +347,14 @@ extern "C" int dcvc_channel_mean(const float *src, int32_t src_cs, float *mean, 
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(channel_partial, dim3(MB, N), dim3(256), 0, st, src, src_cs, scratch, HW, C);
     hipLaunchKernelGGL(channel_finish, dim3(N, (C + 15) / 16), dim3(256), 0, st, scratch, mean, HW, C);
+    RET_LAUNCH();
+}
+
+extern "C" int dcvc_channel_mean_finish(const float *chan_partial, int32_t parts, int32_t row_stride, float *mean, int32_t N,
+                                        int32_t C, int32_t HW, void *stream) {
+    if (!chan_partial || !mean || parts <= 0 || row_stride < C || N <= 0 || C <= 0 || HW <= 0) return DCVC_E_ARG;
+    hipLaunchKernelGGL(channel_finish_rows, dim3(N, (C + 15) / 16), dim3(256), 0, (hipStream_t)stream, chan_partial, parts,
+                       row_stride, mean, HW, C);
     RET_LAUNCH();
 }
 

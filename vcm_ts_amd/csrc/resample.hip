@@ -77,6 +77,51 @@ __global__ void warp_vec4(const float *__restrict__ src, int src_cs, const float
     *(f32x4 *)(out + pix * out_cs + c4 * 4) = r;
 }
 
+// The wave-shuffle form for power-of-two channel groups: the G lanes that share a pixel (G = C/4 lanes of
+// 4 channels each) need the same four tap weights and source offsets.  Only the group's first lane loads the
+// flow vector and does the coordinate arithmetic (two divisions, two floors, the clamps); the other lanes
+// receive the six results through ds_swizzle broadcasts inside their 16- or 32-lane row -- no LDS memory, no
+// repeated flow loads -- and spend their cycles on the 4 x 16-byte gathers.
+template <int G>
+__global__ void warp_shfl(const float *__restrict__ src, int src_cs, const float *__restrict__ flow, int flow_cs,
+                          float *__restrict__ out, int out_cs, int N, int H, int W) {
+    static_assert(G >= 2 && G <= 32 && (G & (G - 1)) == 0, "lanes per pixel");
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t total = (int64_t)N * H * W * G;
+    if (gid >= total) return;  // whole groups leave together (256 % G == 0)
+    const int c4 = (int)(gid & (G - 1));
+    const int64_t pix = gid / G;
+    const int64_t n = pix / ((int64_t)W * H);
+    float wnw = 0.f, wne = 0.f, wsw = 0.f, wse = 0.f;
+    int off = 0, step = 0;
+    if (c4 == 0) {
+        const int x = (int)(pix % W);
+        const int y = (int)((pix / W) % H);
+        const float *fp = flow + pix * flow_cs;
+        const Tap t = make_tap(fp[0], fp[1], x, y, W, H);
+        wnw = t.nw, wne = t.ne, wsw = t.sw, wse = t.se;
+        off = t.y0 * W + t.x0;
+        step = (t.x1 - t.x0) | ((t.y1 - t.y0) << 1);
+    }
+    // bit-mode swizzle: source lane = lane & ~(G - 1) within each half of the wave
+    constexpr int PAT = 0x1F & ~(G - 1);
+    wnw = __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, wnw), PAT));
+    wne = __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, wne), PAT));
+    wsw = __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, wsw), PAT));
+    wse = __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, wse), PAT));
+    off = __builtin_amdgcn_ds_swizzle(off, PAT);
+    step = __builtin_amdgcn_ds_swizzle(step, PAT);
+    const int64_t dx = (int64_t)(step & 1) * src_cs, dy = (int64_t)(step >> 1) * W * src_cs;
+    const float *b = src + (n * (int64_t)H * W + off) * src_cs + c4 * 4;
+    const f32x4 vnw = *(const f32x4 *)b;
+    const f32x4 vne = *(const f32x4 *)(b + dx);
+    const f32x4 vsw = *(const f32x4 *)(b + dy);
+    const f32x4 vse = *(const f32x4 *)(b + dy + dx);
+    // same expression as warp_vec4: bit-identical results
+    const f32x4 r = vnw * wnw + vne * wne + vsw * wsw + vse * wse;
+    *(f32x4 *)(out + pix * out_cs + c4 * 4) = r;
+}
+
 __global__ void warp_scalar(const float *__restrict__ src, int src_cs, const float *__restrict__ flow, int flow_cs,
                             float *__restrict__ out, int out_cs, int N, int H, int W, int C) {
     const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -211,8 +256,16 @@ extern "C" int dcvc_warp(const float *src, int32_t src_cs, const float *flow, in
                      !((uintptr_t)out & 15);
     if (vec) {
         const int64_t total = (int64_t)N * H * W * (C / 4);
-        hipLaunchKernelGGL(warp_vec4, dim3(nblk(total, 256)), dim3(256), 0, st, src, src_cs, flow, flow_cs, out, out_cs,
-                           N, H, W, C / 4);
+        const dim3 grid(nblk(total, 256)), blk(256);
+        switch (C / 4) {  // wave-shuffle kernel for power-of-two channel groups, else every lane computes its tap
+            case 2: hipLaunchKernelGGL(warp_shfl<2>, grid, blk, 0, st, src, src_cs, flow, flow_cs, out, out_cs, N, H, W); break;
+            case 4: hipLaunchKernelGGL(warp_shfl<4>, grid, blk, 0, st, src, src_cs, flow, flow_cs, out, out_cs, N, H, W); break;
+            case 8: hipLaunchKernelGGL(warp_shfl<8>, grid, blk, 0, st, src, src_cs, flow, flow_cs, out, out_cs, N, H, W); break;
+            case 16: hipLaunchKernelGGL(warp_shfl<16>, grid, blk, 0, st, src, src_cs, flow, flow_cs, out, out_cs, N, H, W); break;
+            case 32: hipLaunchKernelGGL(warp_shfl<32>, grid, blk, 0, st, src, src_cs, flow, flow_cs, out, out_cs, N, H, W); break;
+            default:
+                hipLaunchKernelGGL(warp_vec4, grid, blk, 0, st, src, src_cs, flow, flow_cs, out, out_cs, N, H, W, C / 4);
+        }
     } else {
         const int64_t total = (int64_t)N * H * W * C;
         hipLaunchKernelGGL(warp_scalar, dim3(nblk(total, 256)), dim3(256), 0, st, src, src_cs, flow, flow_cs, out,

@@ -364,16 +364,17 @@ class Engine:
                 and all(c % 16 == 0 for c in pk.seg_C))
 
     def conv(self, pk: PackedConv, srcs, out: View, stride=1, in_slope=None, out_slope=None, res: View = None,
-             gate: torch.Tensor = None, res2: View = None):
+             gate: torch.Tensor = None, res2: View = None, chan_partial: torch.Tensor = None):
         """out: an fp32 view (its `twin`, if any, is written by the same launch with the twin's
-        activation) or an s16-only view."""
+        activation) or an s16-only view.  chan_partial: buffer from chan_partial_buf() that receives the
+        per-workgroup channel sums of the output (fused SE squeeze)."""
         want16 = out if out.fmt == "s16" else out.twin
-        if self.s16_capable(pk, stride):
+        if chan_partial is None and self.s16_capable(pk, stride):
             s16_srcs = [s.s16(in_slope) for s in srcs]
             if all(v is not None for v in s16_srcs):
                 return self._conv_s16(pk, srcs, s16_srcs, out, out_slope, res, gate, res2)
         assert out.fmt == "f32" and all(s.fmt == "f32" for s in srcs), ("s16-only tensor reached the fp32 kernel", pk.key)
-        self._conv_f32(pk, srcs, out, stride, in_slope, out_slope, res, gate, res2)
+        self._conv_f32(pk, srcs, out, stride, in_slope, out_slope, res, gate, res2, chan_partial)
         if want16 is not None and self.s16_enabled():
             self.s16_pack_into(out, want16)
         return out
@@ -437,8 +438,15 @@ class Engine:
             self.profile_detail.append((ev0, ev1, flops, f"k{pk.ks}s{stride}{tag} {pk.seg_C}->{pk.Cout}{'ps' if pk.ps else ''} "
                                                          f"{s0.H}x{s0.W}"))
 
+    def chan_partial_buf(self, name, pk: PackedConv, out: View, stride=1):
+        """(buffer, rows per image) for the fused channel sums of a convolution writing `out`."""
+        parts = int(self.L.dcvc_conv_chan_partial_parts(pk.ks, stride, out.H, out.W))
+        if parts <= 0:
+            raise lib.KernelError("conv_chan_partial_parts")
+        return self.fbuf(name + ".chan_partial", out.N * parts * pk.Cout_pad), parts
+
     def _conv_f32(self, pk: PackedConv, srcs, out: View, stride=1, in_slope=None, out_slope=None, res: View = None,
-                  gate: torch.Tensor = None, res2: View = None):
+                  gate: torch.Tensor = None, res2: View = None, chan_partial: torch.Tensor = None):
         a = lib.ConvArgs()
         assert len(srcs) == len(pk.seg_C)
         s0 = srcs[0]
@@ -469,6 +477,8 @@ class Engine:
             a.res2, a.res2_cs = res2.ptr, res2.cs
         if self.range_check and self.precision == "fp16x3":
             a.status = self.status_word().data_ptr()
+        if chan_partial is not None:
+            a.chan_partial = chan_partial.data_ptr()
         self._launch_conv(lambda: lib.check(self.L.dcvc_conv2d(C.byref(a), self.stream()), "conv2d"), pk, s0, Ho, Wo, stride,
                           res, res2)
         self.calls += 1
@@ -518,13 +528,20 @@ class Engine:
         return out
 
     # ------------------------------------------------------------------ SE
-    def se_gate(self, name, t: View, w1: torch.Tensor, w2: torch.Tensor) -> torch.Tensor:
+    def se_gate(self, name, t: View, w1: torch.Tensor, w2: torch.Tensor, partial=None) -> torch.Tensor:
+        """SELayer gate of t.  partial = (buffer, rows, row stride) when the convolution that produced t
+        already summed its channels (conv(..., chan_partial=...)): no pass over t at all."""
         N, C_ = t.N, t.C
-        scratch = self.fbuf("se_scratch", N * 2048 * 256, scratch=True)
         mean = self.fbuf(name + ".mean", N * C_)
         gate = self.fbuf(name + ".gate", N * C_)
-        lib.check(self.L.dcvc_channel_mean(t.ptr, t.cs, mean.data_ptr(), scratch.data_ptr(), N, t.HW, C_,
-                                           self.stream()), "channel_mean")
+        if partial is not None:
+            buf, parts, stride = partial
+            lib.check(self.L.dcvc_channel_mean_finish(buf.data_ptr(), parts, stride, mean.data_ptr(), N, C_, t.HW,
+                                                      self.stream()), "channel_mean_finish")
+        else:
+            scratch = self.fbuf("se_scratch", N * 2048 * 256, scratch=True)
+            lib.check(self.L.dcvc_channel_mean(t.ptr, t.cs, mean.data_ptr(), scratch.data_ptr(), N, t.HW, C_,
+                                               self.stream()), "channel_mean")
         lib.check(self.L.dcvc_se_gate(mean.data_ptr(), w1.data_ptr(), w2.data_ptr(), gate.data_ptr(), N, C_,
                                       w1.shape[0], self.stream()), "se_gate")
         self.calls += 2

@@ -34,7 +34,9 @@ class Net:
         return self.e.buf(f"{self.tag}/{name}", N, H, W, C, cs=cs, zero=zero)
 
     def conv(self, name, srcs, out: View = None, stride=1, in_slope=None, out_slope=None, ps=False, res=None,
-             gate=None, res2=None, out_name=None, cin_slice=None) -> View:
+             gate=None, res2=None, out_name=None, cin_slice=None, want_chan_sums=False):
+        """want_chan_sums: also return (buffer, rows, row stride) of the output's per-workgroup channel sums
+        (fused SE squeeze; not while a training tape records, which keeps the separate reduction)."""
         if isinstance(srcs, View):
             srcs = [srcs]
         w = self.p(name + ".weight")
@@ -47,6 +49,14 @@ class Net:
             Wo = (s0.W + 2 * pad - pk.ks) // stride + 1
             m = 2 if ps else 1
             out = self.buf(out_name or name, N=s0.N, H=Ho * m, W=Wo * m, C=pk.Cout // 4 if ps else pk.Cout)
+        if want_chan_sums:
+            partial = None
+            if self.e.tape is None and not ps and out.cs % 4 == 0:
+                buf, parts = self.e.chan_partial_buf(f"{self.tag}/{name}", pk, out, stride)
+                partial = (buf, parts, pk.Cout_pad)
+            v = self.e.conv(pk, srcs, out, stride=stride, in_slope=in_slope, out_slope=out_slope, res=res, gate=gate,
+                            res2=res2, chan_partial=None if partial is None else partial[0])
+            return v, partial
         return self.e.conv(pk, srcs, out, stride=stride, in_slope=in_slope, out_slope=out_slope, res=res, gate=gate,
                            res2=res2)
 
@@ -106,9 +116,9 @@ class Net:
     def se_block(self, name, srcs, out: View = None) -> View:
         """ConvBlockResidual: up_dim(x) + conv.2(leaky(conv.0(x))) * SE gate."""
         a = self.conv(f"{name}.conv.0", srcs, out_slope=0.01)
-        t = self.conv(f"{name}.conv.2", a)
+        t, sums = self.conv(f"{name}.conv.2", a, want_chan_sums=True)  # SE squeeze rides on this launch's epilogue
         gate = self.e.se_gate(f"{self.tag}/{name}", t, self.p(f"{name}.conv.3.fc.0.weight"),
-                              self.p(f"{name}.conv.3.fc.2.weight"))
+                              self.p(f"{name}.conv.3.fc.2.weight"), partial=sums)
         return self.conv(f"{name}.up_dim", srcs, out=out, res=t, gate=gate)
 
     def unet(self, name, x: View, out: View = None) -> View:
