@@ -292,6 +292,8 @@ def main():
                     help="encode: BASELINE configs[1] (the headline metric, default); decode: the same GOPs through "
                          "decompress (payloads made once, untimed); train: configs[2]/[3], one optimiser step of "
                          "trainer.py / trainer_multi.py per bench step (batch 4 of 256x256 per GPU, DDP over RCCL)")
+    ap.add_argument("--no-extra-workloads", action="store_true",
+                    help="N=1 encode run: skip the short decode and training-step measurements added to the JSON line")
     ap.add_argument("--lenient-parity", action="store_true",
                     help="do not exit non-zero when the fast mode misses the 1e-4 tolerance against the fp32 mode")
     args = ap.parse_args()
@@ -495,6 +497,25 @@ def main():
                                      "(north_star: PSNR/bpp within 1e-4); a picture deep in the GOP may differ more when one "
                                      "symbol rounds the other way (printed as max over pictures)"},
             "roofline": roof32, "note": "same GOP (stream 0's sequence), one stream"}
+    if world == 1 and not args.no_extra_workloads:
+        # the other two workloads of this path, measured by the SAME command the driver runs (short versions
+        # of --workload decode / --workload train), so that they are not builder-only numbers
+        coded = [r[0] for r in cenc.encode_gops(seqs, q_i, q_mv, q_y)]
+        cenc.decode_gops([c[:4] for c in coded], args.height, args.width)  # decoder-side buffers
+        dtd, _ = timed_region(lambda: cenc.decode_gops(coded, args.height, args.width), dev)
+        out["decode"] = {"value": round(K * args.gop / dtd, 3), "unit": "frames/s", "ms_per_step": round(dtd * 1e3, 2),
+                         "workload": f"decode of the same {K} GOPs (reference bitstream: 3 / 6 host rANS round trips per I / P "
+                                     "picture), one host thread and HIP stream per GOP; = bench.py --workload decode"}
+        del coded
+        for e_ in cenc.encoders:  # free the 1080p workspaces before the training model allocates its own
+            e_.i_net.engine().release()
+            e_.p_net.engine().release()
+        torch.cuda.empty_cache()
+        targs = argparse.Namespace(**vars(args))
+        targs.steps, targs.warmup, targs.no_cpu_baseline = 5, 2, True
+        tr = train_workload(targs, dev, rank, world)
+        out["train"] = {"value": tr["value"], "unit": tr["unit"], "ms_per_step": tr["ms_per_step"], "steps": 5,
+                        "workload": tr["config"]["workload"] + "; = bench.py --workload train", "roofline_frac": tr["roofline"]["frac"]}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         ph, pw = (args.cpu_size if args.cpu_size else seq[0].shape[-2:])
         cores = host_cores()

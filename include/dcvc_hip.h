@@ -264,6 +264,19 @@ int dcvc_factorized_bits(const float *z_hat, int32_t z_cs, const float *params, 
 int dcvc_sq_err(const float *a, int32_t a_cs, const float *b, int32_t b_cs, float *out, float *scratch, int32_t N,
                 int32_t HW, int32_t C, void *stream);
 
+/* ---- update(): entropy-model CDF tables built on the device (opt-in) -------------------------
+ * GaussianEncoder.update (entropy_models.py:224-262) / BitEstimator.update (:119-174) incl. pmf_to_quantized_cdf
+ * (ops.cpp:24-82).  Rows have dcvc_cdf_table_cols() int32 columns, zero-padded; sizes = symbols + 2, offsets =
+ * -centre as CdfHelper stores them.  Device libm is not torch-CPU's: an entry whose probability sits on a
+ * rounding boundary may differ by one count from the reference's table (valid, self-consistent, NOT for streams
+ * a reference decoder must read -- those use the host builder, which is integer-identical). */
+int32_t dcvc_cdf_table_cols(void);
+/* scales: the 256 fp32 scale levels (device); kind 0 Laplace, 1 Gaussian */
+int dcvc_build_scale_cdfs(const float *scales, int32_t n_scales, int32_t kind, int32_t *cdf, int32_t *sizes,
+                          int32_t *offsets, void *stream);
+/* params: (11, C) block as for dcvc_factorized_bits */
+int dcvc_build_factorized_cdfs(const float *params, int32_t C, int32_t *cdf, int32_t *sizes, int32_t *offsets, void *stream);
+
 const char *dcvc_hip_version(void);
 
 #ifdef __cplusplus

@@ -109,11 +109,13 @@ int dcvc_mask_accumulate(const float *src, int32_t src_cs, const float *x, int32
 int dcvc_add_planes(const float *a, int32_t a_cs, const float *b, int32_t b_cs, float *out, int32_t out_cs,
                     int64_t npix, int32_t C, void *stream);
 
-/* dsrc (atomic +=, may be NULL) and dflow (+=, 2 channels, may be NULL) of dcvc_warp */
+/* dsrc (+=, may be NULL) and dflow (+=, 2 channels, may be NULL) of dcvc_warp.  The source scatter is summed in
+ * 64-bit fixed point (2^-36 steps) so that the result is independent of the order the atomics land in:
+ * fix_scratch = N*H*W*C 8-byte words, ALL ZERO on entry, left all zero on return (required when dsrc != NULL). */
 int dcvc_warp_bwd(const float *src, int32_t src_cs, const float *flow, int32_t flow_cs, const float *dout,
                   int32_t dout_cs, float *dsrc, int32_t dsrc_cs, float *dflow, int32_t dflow_cs, int32_t N, int32_t H,
-                  int32_t W, int32_t C, void *stream);
-/* dsrc += adjoint of dcvc_up2 (dout is (N, 2H, 2W, .)); atomic */
+                  int32_t W, int32_t C, void *fix_scratch, void *stream);
+/* dsrc += adjoint of dcvc_up2 (dout is (N, 2H, 2W, .)); gathered per source element, no atomics */
 int dcvc_up2_bwd(const float *dout, int32_t dout_cs, float *dsrc, int32_t dsrc_cs, int32_t N, int32_t H, int32_t W,
                  int32_t C, float scale, void *stream);
 /* dsrc (N, H, W, .) += scale/4 * dout(y/2, x/2) */

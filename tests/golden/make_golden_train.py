@@ -1,4 +1,4 @@
-"""Generate tests/golden/train_64.npz by running the REFERENCE's training-mode forward and
+"""Generate tests/golden/train_64.npz and train_256_b4.npz by running the REFERENCE's training-mode forward and
 torch.autograd backward (build container only; see tests/golden/make_golden.py for the import rules).
 
 Two consecutive P pictures of a 64x64 batch-2 clip: the first after an "I picture" (DPB holds
@@ -6,6 +6,9 @@ only ref_frame), the second with the full (detached) DPB -- the reference's `sin
 recursion (core/model/dcvc_hem.py:189-196).  Stored: the uniform draws add_noise made (so that
 a checker can replay them), every scalar output, the loss and, per parameter, the gradient's
 L2 norm and its first 8 values; gradients of the per-sample q-scales in full.
+
+train_256_b4 is BASELINE configs[2]'s shape: batch 4 of 256x256 pictures, one rate point per sample (the
+model's first four q-scales, lambdas 85 / 170 / 380 / 840 as core/config/defaults.py).
 
     python tests/golden/make_golden_train.py
 """
@@ -28,16 +31,21 @@ OUT = os.path.join(ROOT, "tests", "golden")
 LAMBDA, ME_WEIGHT = 50.0, 10.0   # loss = mean(bpp + LAMBDA * mse + ME_WEIGHT * me_mse)
 
 
-def main():
+def main(N=2, size=64, out_name="train_64", lambdas=None):
     DMC, _ = load(with_cxx=False)
-    N, size = 2, 64
     net = DMC(anchor_num=4)
     net.load_state_dict(seeded_state_dict(dmc_spec()))
     net.train()
     fr = frames(3, N * 3, size, size)
     x0, x1, x2 = (torch.from_numpy(fr[k * N:(k + 1) * N]) for k in range(3))
-    q_mv = torch.tensor([1.0, 0.8]).view(N, 1, 1, 1)
-    q_y = torch.tensor([1.2, 0.9]).view(N, 1, 1, 1)
+    if lambdas is None:
+        q_mv = torch.tensor([1.0, 0.8]).view(N, 1, 1, 1)
+        q_y = torch.tensor([1.2, 0.9]).view(N, 1, 1, 1)
+        lam = torch.full((N,), LAMBDA)
+    else:  # one rate point per sample (core/data/__init__.py:75)
+        q_mv = net.mv_y_q_scale[:N].detach().clone().view(N, 1, 1, 1)
+        q_y = net.y_q_scale[:N].detach().clone().view(N, 1, 1, 1)
+        lam = torch.tensor(lambdas, dtype=torch.float32)
     draws = []
     orig = net.add_noise
 
@@ -47,7 +55,9 @@ def main():
         return out
 
     net.add_noise = add_noise
-    fx = {"meta": np.array([N, size, LAMBDA, ME_WEIGHT], np.float64), "names": np.array(list(dmc_spec().keys()))}
+    fx = {"meta": np.array([N, size, LAMBDA, ME_WEIGHT], np.float64), "names": np.array(list(dmc_spec().keys())),
+          "lambdas": lam.numpy().astype(np.float64), "q_mv": q_mv.reshape(-1).numpy().astype(np.float64),
+          "q_y": q_y.reshape(-1).numpy().astype(np.float64)}
     dpb = {"ref_frame": x0, "ref_feature": None, "ref_y": None, "ref_mv_y": None}
     for step, x in enumerate((x1, x2)):
         torch.manual_seed(100 + step)
@@ -55,7 +65,7 @@ def main():
         net.zero_grad(set_to_none=True)
         qm, qy = q_mv.clone().requires_grad_(), q_y.clone().requires_grad_()
         out = net.forward_one_frame(x, dpb, qm, qy)
-        loss = torch.mean(out["bpp"] + LAMBDA * out["mse"] + ME_WEIGHT * out["me_mse"])
+        loss = torch.mean(out["bpp"] + lam * out["mse"] + ME_WEIGHT * out["me_mse"])
         loss.backward()
         p = f"s{step}_"
         for key, t in zip(("y", "mv_y", "z", "mv_z"), draws):   # order of the calls at video_model.py:547-550
@@ -82,8 +92,10 @@ def main():
         fx[p + "grad_head"] = np.stack(heads)
         dpb = {k: v.detach() for k, v in out["dpb"].items()}
         print(f"step {step}: loss {loss.item():.6f}, {sum(n >= 0 for n in norms)} parameter gradients")
-    np.savez_compressed(os.path.join(OUT, "train_64.npz"), **fx)
+    np.savez_compressed(os.path.join(OUT, out_name + ".npz"), **fx)
 
 
 if __name__ == "__main__":
+    torch.set_num_threads(8)
     main()
+    main(4, 256, "train_256_b4", (85.0, 170.0, 380.0, 840.0))

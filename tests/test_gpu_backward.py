@@ -73,23 +73,26 @@ def test_frame_gradients_match_oracle_autograd(precision):
     assert G.frame_case(size=64, N=2, second=True, verbose=False, precision=precision) < 2e-3
 
 
-def test_frame_gradients_match_reference_fixture():
-    """HIP path against the numbers the reference itself produced (loss, bpp/mse, every
-    parameter's gradient norm and first values, q-scale gradients)."""
+@pytest.mark.parametrize("name", ["train_64", "train_256_b4"])
+def test_frame_gradients_match_reference_fixture(name):
+    """HIP path against the numbers the reference itself produced (loss, bpp/mse, every parameter's gradient
+    norm and first values, q-scale gradients): a 64x64 batch-2 clip and BASELINE configs[2]'s shape, batch 4 of
+    256x256 with one rate point / lambda per sample."""
     from tests.util import golden
     from vcm_ts_amd.dmc import DMC
     from vcm_ts_amd.synthetic import frames
 
-    fx = golden("train_64")
-    N, size, lam, me_w = int(fx["meta"][0]), int(fx["meta"][1]), float(fx["meta"][2]), float(fx["meta"][3])
+    fx, fx_name = golden(name), name
+    N, size, me_w = int(fx["meta"][0]), int(fx["meta"][1]), float(fx["meta"][3])
     dev = torch.device("cuda:0")
     m = DMC(precision="fp32").to(dev).train()
     for p in m.parameters():
         p.requires_grad_(True)
     fr = frames(3, N * 3, size, size)
     x0, x1, x2 = (torch.from_numpy(fr[k * N:(k + 1) * N]).to(dev) for k in range(3))
-    q_mv = torch.tensor([1.0, 0.8], device=dev).view(N, 1, 1, 1)
-    q_y = torch.tensor([1.2, 0.9], device=dev).view(N, 1, 1, 1)
+    q_mv = torch.from_numpy(fx["q_mv"]).float().to(dev).view(N, 1, 1, 1)
+    q_y = torch.from_numpy(fx["q_y"]).float().to(dev).view(N, 1, 1, 1)
+    lam = torch.from_numpy(fx["lambdas"]).float().to(dev)
     dpb = {"ref_frame": x0, "ref_feature": None, "ref_y": None, "ref_mv_y": None}
     params = dict(m.named_parameters())
     for step, x in enumerate((x1, x2)):
@@ -107,6 +110,7 @@ def test_frame_gradients_match_reference_fixture():
         np.testing.assert_allclose(qy.grad.cpu().numpy(), fx[p + "dq_y"], rtol=5e-3, atol=1e-6)
         names = [str(n) for n in fx[p + "grad_names"]]
         sq_ref = sq_diff = 0.0
+        worst = ("", 0.0)
         for i, name in enumerate(names):
             want = float(fx[p + "grad_norm"][i])
             g = params[name].grad
@@ -121,6 +125,10 @@ def test_frame_gradients_match_reference_fixture():
                                        err_msg=name)
             sq_ref += want * want
             sq_diff += (got - want) ** 2
+            if want > 1e-6 and abs(got - want) / want > worst[1]:
+                worst = (name, abs(got - want) / want)
+        print(f"\n[{fx_name} step {step}] gradient norms vs the reference: whole {sq_diff ** 0.5 / sq_ref ** 0.5:.2e}, "
+              f"worst tensor {worst[0]} {worst[1]:.2e}")
         assert sq_diff ** 0.5 <= 2e-3 * sq_ref ** 0.5
         dpb = {k: v.detach() for k, v in out["dpb"].items()}
     m._noise_override = None
@@ -152,3 +160,45 @@ def test_frozen_parameters_get_no_gradient_and_dpb_inputs_get_one():
     (out2["bpp"] + 100 * out2["mse"]).mean().backward()
     for k, v in dpb.items():
         assert v.grad is not None and torch.isfinite(v.grad).all() and float(v.grad.abs().sum()) > 0, k
+
+
+def test_training_step_is_bit_reproducible():
+    """Two runs of the same training-mode picture (first-after-I and with a full DPB, batch 2) give
+    bit-identical losses and gradients: grid_sample's source scatter is summed in 64-bit fixed point, the
+    bilinear upsampling adjoint is a gather, every other reduction has a fixed order (no float atomics left)."""
+    from vcm_ts_amd.dmc import DMC
+    from vcm_ts_amd.synthetic import frames
+
+    dev = torch.device("cuda:0")
+    m = DMC(precision="fp16x3").to(dev).train()
+    for p in m.parameters():
+        p.requires_grad_(True)
+    N, size = 2, 128
+    fr = frames(9, N * 3, size, size)
+    x0, x1, x2 = (torch.from_numpy(fr[k * N:(k + 1) * N]).to(dev) for k in range(3))
+    g = torch.Generator().manual_seed(3)
+    noise = {"y": torch.rand(N, 96, size // 16, size // 16, generator=g) - 0.5,
+             "mv_y": torch.rand(N, 64, size // 16, size // 16, generator=g) - 0.5,
+             "z": torch.rand(N, 64, size // 64, size // 64, generator=g) - 0.5,
+             "mv_z": torch.rand(N, 64, size // 64, size // 64, generator=g) - 0.5}
+    m._noise_override = noise
+
+    def run():
+        grads = []
+        dpb = {"ref_frame": x0, "ref_feature": None, "ref_y": None, "ref_mv_y": None}
+        for x in (x1, x2):
+            m.zero_grad(set_to_none=True)
+            out = m.forward_one_frame(x, dpb, 1.0, 1.0)
+            loss = torch.mean(out["bpp"] + 256.0 * out["mse"] + out["me_mse"])
+            loss.backward()
+            grads.append((loss.detach().clone(), {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}))
+            dpb = {k: v.detach() for k, v in out["dpb"].items()}
+        return grads
+
+    a, b = run(), run()
+    for (la, ga), (lb, gb) in zip(a, b):
+        assert torch.equal(la, lb)
+        assert ga.keys() == gb.keys() and len(ga) > 300
+        for k in ga:
+            assert torch.equal(ga[k], gb[k]), k
+    m._noise_override = None

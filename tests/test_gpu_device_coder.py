@@ -164,3 +164,48 @@ def test_device_coder_with_concurrent_gop_streams():
         coded, _, dpb = host.encode_gop(seqs[k], 1.0, 1.0, 1.0)
         assert all(c[2][:4] == E.DRANS_MAGIC for c in res[k][0])
         assert torch.equal(enc_ref[k], dpb["ref_frame"]) and torch.equal(recs[k][-1], dpb["ref_frame"]), k
+
+
+def test_update_on_the_device_builds_the_reference_tables():
+    """update(device_tables=True): GaussianEncoder.update / BitEstimator.update + pmf_to_quantized_cdf as GPU
+    kernels, against the tables the REFERENCE built (tests/golden/tables.npz).  Structure must be
+    identical (row lengths, offsets) and every row a valid 16-bit CDF; the integer entries are compared one by
+    one and the mismatch count printed.  They cannot be guaranteed equal: the reference evaluates the CDFs with
+    torch-CPU's fp32 expm1 / erf / tanh (SLEEF), the kernels with the device's, and a probability whose
+    round(p * 2^16) sits on a boundary moves by one count (bounded here at 0.2 % of the entries, each by <= 2
+    counts, shifted mass conserved).  A stream coded and decoded with the device-built tables round-trips."""
+    from vcm_ts_amd.dmc import DMC
+    from vcm_ts_amd.intra import IntraNoAR
+
+    fx = golden("tables")
+    d, i = DMC().to(DEV).eval(), IntraNoAR().to(DEV).eval()
+    d.update(device_tables=True)
+    i.update(device_tables=True)
+    total = bad = 0
+    for net, pairs in ((d, (("scale", "dmc_scale"), ("bit_estimator_z", "dmc_z"), ("bit_estimator_z_mv", "dmc_zmv"))),
+                       (i, (("scale", "intra_scale"), ("bit_estimator_z", "intra_z")))):
+        for name, key in pairs:
+            cdf, ln, off = net._tables[name]
+            np.testing.assert_array_equal(ln, fx[key + "_len"], err_msg=key)
+            np.testing.assert_array_equal(off, fx[key + "_off"], err_msg=key)
+            want = fx[key + "_cdf"]
+            assert cdf.shape == want.shape, (key, cdf.shape, want.shape)
+            for r in range(cdf.shape[0]):
+                row = cdf[r, : ln[r]]
+                assert row[0] == 0 and row[-1] == 65536 and np.all(np.diff(row) >= 1), (key, r)
+                assert np.all(cdf[r, ln[r]:] == 0)
+            diff = cdf != want
+            total += diff.size
+            bad += int(diff.sum())
+            assert np.abs(cdf.astype(np.int64) - want).max() <= 2, key
+            print(f"\n  {key:12s}: {int(diff.sum()):5d} of {diff.size} entries differ from the reference table")
+    assert bad <= 0.002 * total, (bad, total)
+    fr = frames(33, 3, 128, 192)
+    seq = [torch.from_numpy(fr[t : t + 1]).to(DEV) for t in range(3)]
+    ci = i.compress(seq[0], 1.0)
+    di = i.decompress(ci["bit_stream"], 128, 192, 1.0)
+    assert torch.equal(di["x_hat"], ci["x_hat"])
+    dpb = {"ref_frame": ci["x_hat"], "ref_feature": None, "ref_y": None, "ref_mv_y": None}
+    c = d.compress(seq[1], dpb, 1.0, 1.0)
+    r = d.decompress(dpb, c["bit_stream"], 128, 192, 1.0, 1.0)
+    assert torch.equal(r["dpb"]["ref_frame"], c["dpb"]["ref_frame"])

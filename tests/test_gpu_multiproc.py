@@ -84,6 +84,22 @@ def test_bench_runs_with_world_size_two():
     assert {"roofline", "metric", "unit", "ms_per_step", "config"} <= set(d)
 
 
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` by itself (no torchrun around it, the form the driver uses): the parent starts
+    one rank per GPU as a child torch.distributed.run before touching the GPU and hands back its exit code; a
+    world size that contradicts --gpus is refused."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--height", "128",
+           "--width", "192", "--gop", "3", "--dist-backend", "gloo", "--no-cpu-baseline"]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["value"] > 0
+    bad = subprocess.run(cmd[:3] + ["1"] + cmd[4:], env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"), capture_output=True,
+                         text=True, timeout=120)
+    assert bad.returncode != 0 and "WORLD_SIZE" in (bad.stderr + bad.stdout)
+
+
 DDP_WORKER = r"""
 import os, sys, pickle
 sys.path.insert(0, os.environ["DCVC_ROOT"])

@@ -6,6 +6,7 @@ product path (libdcvc_rans entropy coding of seeded symbol planes) -- the device
 GPU and is covered by the -m gpu tests."""
 import os
 import socket
+import subprocess
 import sys
 
 import numpy as np
@@ -92,3 +93,22 @@ def test_two_rank_gloo_run_matches_single_process():
 def test_timed_region_single_process():
     dt, r = timed_region(lambda: 41 + 1)
     assert r == 42 and dt >= 0
+
+
+def test_bench_self_launch_starts_one_rank_per_gpu_and_propagates_failure():
+    """`python bench.py --gpus 2` without torchrun around it: the parent must start two ranks as a child
+    torch.distributed.run (env:// rendezvous on 127.0.0.1) and return the child's exit code.  There is no GPU
+    here, so each rank stops at "needs a GPU" -- which is exactly what shows that two ranks were started,
+    that they got their RANK / WORLD_SIZE and that the failure came back as a non-zero exit."""
+    import re
+
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["CUDA_VISIBLE_DEVICES"] = env["HIP_VISIBLE_DEVICES"] = ""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                        "--dist-backend", "gloo"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert len(re.findall(r"bench\.py needs a GPU", r.stderr + r.stdout)) >= 2, (r.stderr + r.stdout)[-1500:]
+    # a world size that contradicts --gpus is refused before anything else happens
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"],
+                         env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"), capture_output=True, text=True, timeout=120)
+    assert bad.returncode != 0 and "WORLD_SIZE=2" in bad.stderr + bad.stdout

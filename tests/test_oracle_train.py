@@ -15,8 +15,9 @@ def run_oracle_steps(fx):
     w0 = seeded_state_dict(dmc_spec())
     fr = frames(3, N * 3, size, size)
     x0, x1, x2 = (torch.from_numpy(fr[k * N:(k + 1) * N]) for k in range(3))
-    q_mv = torch.tensor([1.0, 0.8]).view(N, 1, 1, 1)
-    q_y = torch.tensor([1.2, 0.9]).view(N, 1, 1, 1)
+    q_mv = torch.from_numpy(fx["q_mv"]).float().view(N, 1, 1, 1)
+    q_y = torch.from_numpy(fx["q_y"]).float().view(N, 1, 1, 1)
+    lam = torch.from_numpy(fx["lambdas"]).float()
     dpb = {"ref_frame": x0, "ref_feature": None, "ref_y": None, "ref_mv_y": None}
     for step, x in enumerate((x1, x2)):
         p = f"s{step}_"
@@ -31,8 +32,13 @@ def run_oracle_steps(fx):
         dpb = {k: v.detach() for k, v in out["dpb"].items()}
 
 
-def test_training_forward_and_gradients_match_reference():
-    fx = golden("train_64")
+import pytest
+
+
+@pytest.mark.parametrize("name", ["train_64", "train_256_b4"])
+def test_training_forward_and_gradients_match_reference(name):
+    """train_256_b4 = BASELINE configs[2]'s shape (batch 4 of 256x256, one rate point and lambda per sample)."""
+    fx = golden(name)
     for step, p, out, loss, w, qm, qy in run_oracle_steps(fx):
         for key in ("bpp_y", "bpp_z", "bpp_mv_y", "bpp_mv_z", "bpp", "mse", "me_mse"):
             np.testing.assert_allclose(out[key].detach().numpy(), fx[p + key], rtol=3e-5, err_msg=f"{p}{key}")

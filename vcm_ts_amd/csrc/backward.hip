@@ -444,11 +444,27 @@ __device__ __forceinline__ float lin11(int i, int n) {
     return i < n / 2 ? -1.0f + step * (float)i : 1.0f - step * (float)(n - 1 - i);
 }
 
+// Order-independent accumulation for the scatter of grid_sample's backward: contributions are rounded to
+// 2^-36 (range +-1.3e8: rate gradients reach 1e4) and added as integers.
+constexpr float FIX_ONE = 68719476736.f;  // 2^36
+__device__ __forceinline__ void fix_add(unsigned long long *p, float v) {
+    atomicAdd(p, (unsigned long long)__float2ll_rn(v * FIX_ONE));
+}
+
+__global__ void fix_finish_kernel(unsigned long long *__restrict__ fix, float *__restrict__ dst, int dst_cs, int64_t npix, int C) {
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= npix * C) return;
+    const long long v = (long long)fix[gid];
+    fix[gid] = 0;  // left clean for the next call
+    if (v) dst[(gid / C) * dst_cs + gid % C] += (float)((double)v * (1.0 / 68719476736.0));
+}
+
 // One thread per (pixel, channel): scatter into dsrc with atomics, reduce the flow gradient
 // over the channels of a pixel through LDS (a block holds whole pixels: 256 % Cl == 0 or Cl == C loop).
 __global__ void warp_bwd_kernel(const float *__restrict__ src, int src_cs, const float *__restrict__ flow, int flow_cs,
                                 const float *__restrict__ dout, int dout_cs, float *__restrict__ dsrc, int dsrc_cs,
-                                float *__restrict__ dflow, int dflow_cs, int N, int H, int W, int C) {
+                                float *__restrict__ dflow, int dflow_cs, int N, int H, int W, int C,
+                                unsigned long long *__restrict__ fix) {
     const int64_t pix = (int64_t)blockIdx.x * blockDim.y + threadIdx.y;  // blockDim = (Cl, 256 / Cl)
     const bool live = pix < (int64_t)N * H * W;
     float gx_acc = 0.f, gy_acc = 0.f;
@@ -479,10 +495,13 @@ __global__ void warp_bwd_kernel(const float *__restrict__ src, int src_cs, const
             gx_acc += g * (s * (vne - vnw) + nn * (vse - vsw));
             gy_acc += g * (e * (vsw - vnw) + w * (vse - vne));
             if (dsrc) {
-                atomicAdd(&dsrc[pnw * dsrc_cs + c], g * (s * e));
-                if (x1in) atomicAdd(&dsrc[pne * dsrc_cs + c], g * (s * w));
-                if (y1in) atomicAdd(&dsrc[psw * dsrc_cs + c], g * (nn * e));
-                if (x1in && y1in) atomicAdd(&dsrc[pse * dsrc_cs + c], g * (nn * w));
+                // the scatter is data dependent (several output pixels may sample one source pixel): summed as
+                // 64-bit fixed point, whose addition is associative, so the result does not depend on the order
+                // in which the atomics land (float atomics made two runs of the same step differ in the last bits)
+                fix_add(&fix[pnw * C + c], g * (s * e));
+                if (x1in) fix_add(&fix[pne * C + c], g * (s * w));
+                if (y1in) fix_add(&fix[psw * C + c], g * (nn * e));
+                if (x1in && y1in) fix_add(&fix[pse * C + c], g * (nn * w));
             }
         }
         gx_acc *= mx;
@@ -505,25 +524,35 @@ __global__ void warp_bwd_kernel(const float *__restrict__ src, int src_cs, const
     }
 }
 
+// adjoint of up2_kernel as a GATHER: one thread per source element visits the <= 6 x 6 output pixels whose
+// bilinear taps can touch it, recomputes their taps with the forward kernel's arithmetic and adds the matching
+// weights in a fixed order (no atomics: run-to-run identical)
 __global__ void up2_bwd_kernel(const float *__restrict__ dout, int dout_cs, float *__restrict__ dsrc, int dsrc_cs, int N,
                                int H, int W, int C, float scale) {
     const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int Ho = 2 * H, Wo = 2 * W;
-    if (gid >= (int64_t)N * Ho * Wo * C) return;
+    if (gid >= (int64_t)N * H * W * C) return;
     const int c = (int)(gid % C);
     const int64_t pix = gid / C;
-    const int ox = (int)(pix % Wo), oy = (int)((pix / Wo) % Ho);
-    const int64_t n = pix / ((int64_t)Wo * Ho);
-    const float sx = fmaxf(((float)ox + 0.5f) * 0.5f - 0.5f, 0.f), sy = fmaxf(((float)oy + 0.5f) * 0.5f - 0.5f, 0.f);
-    const int x0 = (int)sx, y0 = (int)sy;
-    const int x1 = min(x0 + 1, W - 1), y1 = min(y0 + 1, H - 1);
-    const float lx1 = sx - (float)x0, lx0 = 1.f - lx1, ly1 = sy - (float)y0, ly0 = 1.f - ly1;
-    const float g = dout[pix * dout_cs + c] * scale;
-    float *b = dsrc + n * (int64_t)H * W * dsrc_cs + c;
-    atomicAdd(&b[((int64_t)y0 * W + x0) * dsrc_cs], g * ly0 * lx0);
-    atomicAdd(&b[((int64_t)y0 * W + x1) * dsrc_cs], g * ly0 * lx1);
-    atomicAdd(&b[((int64_t)y1 * W + x0) * dsrc_cs], g * ly1 * lx0);
-    atomicAdd(&b[((int64_t)y1 * W + x1) * dsrc_cs], g * ly1 * lx1);
+    const int sx = (int)(pix % W), sy = (int)((pix / W) % H);
+    const int64_t n = pix / ((int64_t)W * H);
+    const int Ho = 2 * H, Wo = 2 * W;
+    auto weight = [](int o, int s, int L) {  // weight of source index s in output index o (0 if not a tap)
+        const float p = fmaxf(((float)o + 0.5f) * 0.5f - 0.5f, 0.f);
+        const int i0 = (int)p, i1 = min(i0 + 1, L - 1);
+        const float l1 = p - (float)i0, l0 = 1.f - l1;
+        return (i0 == s ? l0 : 0.f) + (i1 == s ? l1 : 0.f);
+    };
+    const float *b = dout + n * (int64_t)Ho * Wo * dout_cs + c;
+    float acc = 0.f;
+    for (int oy = max(0, 2 * sy - 2); oy <= min(Ho - 1, 2 * sy + 3); ++oy) {
+        const float wy = weight(oy, sy, H);
+        if (wy == 0.f) continue;
+        for (int ox = max(0, 2 * sx - 2); ox <= min(Wo - 1, 2 * sx + 3); ++ox) {
+            const float wx = weight(ox, sx, W);
+            if (wx != 0.f) acc += (b[((int64_t)oy * Wo + ox) * dout_cs] * scale) * wy * wx;
+        }
+    }
+    dsrc[pix * dsrc_cs + c] += acc;
 }
 
 __global__ void down2_bwd_kernel(const float *__restrict__ dout, int dout_cs, float *__restrict__ dsrc, int dsrc_cs,
@@ -965,21 +994,25 @@ extern "C" int dcvc_add_planes(const float *a, int32_t a_cs, const float *b, int
 
 extern "C" int dcvc_warp_bwd(const float *src, int32_t src_cs, const float *flow, int32_t flow_cs, const float *dout,
                              int32_t dout_cs, float *dsrc, int32_t dsrc_cs, float *dflow, int32_t dflow_cs, int32_t N,
-                             int32_t H, int32_t W, int32_t C, void *stream) {
+                             int32_t H, int32_t W, int32_t C, void *fix_scratch, void *stream) {
     if (!src || !flow || !dout || (!dsrc && !dflow) || N <= 0 || H <= 1 || W <= 1 || C <= 0) return DCVC_E_ARG;
+    if (dsrc && !fix_scratch) return DCVC_E_ARG;
     int Cl = 1;
     while (Cl * 2 <= C && Cl < 64) Cl *= 2;  // threads per pixel (power of two <= 64)
     const int64_t npix = (int64_t)N * H * W;
     dim3 block(Cl, 256 / Cl);
     hipLaunchKernelGGL(warp_bwd_kernel, dim3(nblk(npix, 256 / Cl)), block, 0, (hipStream_t)stream, src, src_cs, flow,
-                       flow_cs, dout, dout_cs, dsrc, dsrc_cs, dflow, dflow_cs, N, H, W, C);
+                       flow_cs, dout, dout_cs, dsrc, dsrc_cs, dflow, dflow_cs, N, H, W, C, (unsigned long long *)fix_scratch);
+    if (dsrc)
+        hipLaunchKernelGGL(fix_finish_kernel, dim3(nblk(npix * C, 256)), dim3(256), 0, (hipStream_t)stream,
+                           (unsigned long long *)fix_scratch, dsrc, dsrc_cs, npix, C);
     RET_LAUNCH();
 }
 
 extern "C" int dcvc_up2_bwd(const float *dout, int32_t dout_cs, float *dsrc, int32_t dsrc_cs, int32_t N, int32_t H,
                             int32_t W, int32_t C, float scale, void *stream) {
     if (!dout || !dsrc || N <= 0 || H <= 0 || W <= 0 || C <= 0) return DCVC_E_ARG;
-    const int64_t total = (int64_t)N * 4 * H * W * C;
+    const int64_t total = (int64_t)N * H * W * C;
     hipLaunchKernelGGL(up2_bwd_kernel, dim3(nblk(total, 256)), dim3(256), 0, (hipStream_t)stream, dout, dout_cs, dsrc,
                        dsrc_cs, N, H, W, C, scale);
     RET_LAUNCH();

@@ -337,6 +337,118 @@ __global__ void sq_err_kernel(const float *__restrict__ a, int a_cs, const float
     if (threadIdx.x == 0) scratch[(size_t)n * RB + blockIdx.x] = s;
 }
 
+// ---- update(): CDF tables on the device (opt-in) -------------------------------------------
+// GaussianEncoder.update (entropy_models.py:224-262) and BitEstimator.update (:119-174) with the quantiser of
+// EntropyCoder.pmf_to_quantized_cdf (ops.cpp:24-82).  The reference evaluates the Laplace / Normal /
+// factorised CDFs with torch-CPU fp32 kernels (SLEEF); the device's expm1f / erff / expf / tanhf are not the
+// same functions to the last ulp, so a probability next to a rounding boundary of round(p * 2^16) can land in
+// the neighbouring integer: these tables are valid and self-consistent (encoder and decoder of THIS library
+// agree), but interoperable streams use the host-built tables, which are integer-identical to the reference.
+constexpr int kTabCols = 104;  // 2 * 50 + 1 symbols + tail bin + 1, rounded up
+
+__device__ void quantize_row(const float *pmf, int n, uint32_t *cdf) {  // ops.cpp:24-82, serial
+    const float scale = 65536.f;
+    uint32_t total = 0;
+    cdf[0] = 0;
+    for (int i = 0; i < n; ++i) {
+        cdf[i + 1] = (uint32_t)(roundf(pmf[i] * scale) + 0.5f);
+        total += cdf[i + 1];
+    }
+    uint32_t run = 0;
+    for (int i = 0; i <= n; ++i) {
+        run += (uint32_t)((((uint64_t)1 << 16) * cdf[i]) / (total ? total : 1));
+        cdf[i] = run;
+    }
+    cdf[n] = 1u << 16;
+    for (int i = 0; i < n; ++i) {
+        if (cdf[i] != cdf[i + 1]) continue;
+        uint32_t best = ~0u;
+        int donor = -1;
+        for (int j = 0; j < n; ++j) {
+            const uint32_t w = cdf[j + 1] - cdf[j];
+            if (w > 1 && w < best) best = w, donor = j;
+        }
+        if (donor < 0) return;
+        if (donor < i)
+            for (int j = donor + 1; j <= i; ++j) cdf[j]--;
+        else
+            for (int j = i + 1; j <= donor; ++j) cdf[j]++;
+    }
+}
+
+// one block per scale level
+__global__ void scale_cdfs_kernel(const float *__restrict__ scales, int kind, int32_t *__restrict__ cdf,
+                                  int32_t *__restrict__ sizes, int32_t *__restrict__ offsets) {
+    __shared__ float pmf[kTabCols];
+    __shared__ uint32_t q[kTabCols + 1];
+    __shared__ int center;
+    const int row = blockIdx.x, t = threadIdx.x;
+    const float s = scales[row];
+    auto F = [&](float x) { return kind == 0 ? laplace_cdf(x, s) : normal_cdf(x, s); };
+    if (t == 0) center = 50;
+    __syncthreads();
+    if (t >= 2 && t <= 50 && F((float)t) > 0.9999f) atomicMin(&center, t);  // smallest i whose tail is below 1e-4
+    __syncthreads();
+    const int c = center, len = 2 * c + 1;
+    if (t < len) {
+        const float x = (float)(t - c);
+        pmf[t] = F(x + 0.5f) - F(x - 0.5f);
+    }
+    if (t == len) pmf[len] = 2.f * F((float)(-c) - 0.5f);  // tail mass = 2 * lower[0]
+    for (int i = t; i <= kTabCols; i += blockDim.x) q[i] = 0;
+    __syncthreads();
+    if (t == 0) {
+        quantize_row(pmf, len + 1, q);
+        sizes[row] = len + 2;
+        offsets[row] = -c;
+    }
+    __syncthreads();
+    for (int i = t; i < kTabCols; i += blockDim.x) cdf[row * kTabCols + i] = i <= len + 1 ? (int32_t)q[i] : 0;
+}
+
+// one block for all channels of a factorised prior (C <= 256)
+__global__ void factorized_cdfs_kernel(const float *__restrict__ P, int C, int32_t *__restrict__ cdf,
+                                       int32_t *__restrict__ sizes, int32_t *__restrict__ offsets) {
+    extern __shared__ unsigned char smem[];
+    int *lo = (int *)smem, *hi = lo + C;
+    int *max_len = hi + C;
+    float *pmf = (float *)(max_len + 4);
+    const int t = threadIdx.x;
+    for (int c = t; c < C; c += blockDim.x) lo[c] = 50, hi[c] = 50;
+    if (t == 0) *max_len = 0;
+    __syncthreads();
+    for (int k = t; k < C * 49; k += blockDim.x) {
+        const int c = k / 49, i = 2 + k % 49;
+        if (fact_cdf(-(float)i, P, C, c) < 0.0001f) atomicMin(&lo[c], i);
+        if (fact_cdf((float)i, P, C, c) > 0.9999f) atomicMin(&hi[c], i);
+    }
+    __syncthreads();
+    for (int c = t; c < C; c += blockDim.x) atomicMax(max_len, hi[c] + lo[c] + 1);
+    __syncthreads();
+    const int ml = *max_len;
+    for (int k = t; k < C * kTabCols; k += blockDim.x) {
+        const int c = k / kTabCols, j = k % kTabCols, len = hi[c] + lo[c] + 1;
+        float v = 0.f;
+        if (j < len) {
+            const float x = (float)(j - lo[c]);
+            v = fact_cdf(x + 0.5f, P, C, c) - fact_cdf(x - 0.5f, P, C, c);
+        } else if (j == len) {  // tail: lower[0] + (1 - upper[max_len - 1]) over the PADDED sample range (:160-164)
+            v = fact_cdf(-(float)lo[c] - 0.5f, P, C, c) + (1.0f - fact_cdf((float)(ml - 1 - lo[c]) + 0.5f, P, C, c));
+        }
+        pmf[k] = v;
+    }
+    __syncthreads();
+    for (int c = t; c < C; c += blockDim.x) {
+        const int len = hi[c] + lo[c] + 1;
+        uint32_t q[kTabCols + 1];
+        for (int i = 0; i <= kTabCols; ++i) q[i] = 0;
+        quantize_row(pmf + c * kTabCols, len + 1, q);
+        for (int i = 0; i < kTabCols; ++i) cdf[c * kTabCols + i] = i <= len + 1 ? (int32_t)q[i] : 0;
+        sizes[c] = len + 2;
+        offsets[c] = -lo[c];
+    }
+}
+
 }  // namespace
 
 extern "C" int dcvc_channel_mean(const float *src, int32_t src_cs, float *mean, float *scratch, int32_t N, int32_t HW,
@@ -426,6 +538,26 @@ extern "C" int dcvc_dual_prior_dec_apply(const dcvc_dual_prior_args *a, void *st
     if (dual_prior_check(a) || !a->sym) return DCVC_E_ARG;
     const int64_t total = (int64_t)a->N * a->H * a->W * a->C;
     hipLaunchKernelGGL(dual_prior_kernel<2>, dim3(nblk(total, 256)), dim3(256), 0, (hipStream_t)stream, *a, total);
+    RET_LAUNCH();
+}
+
+extern "C" int32_t dcvc_cdf_table_cols(void) { return kTabCols; }
+
+extern "C" int dcvc_build_scale_cdfs(const float *scales, int32_t n_scales, int32_t kind, int32_t *cdf, int32_t *sizes,
+                                     int32_t *offsets, void *stream) {
+    if (!scales || !cdf || !sizes || !offsets || n_scales <= 0 || (kind != 0 && kind != 1)) return DCVC_E_ARG;
+    hipLaunchKernelGGL(scale_cdfs_kernel, dim3(n_scales), dim3(128), 0, (hipStream_t)stream, scales, kind, cdf, sizes, offsets);
+    RET_LAUNCH();
+}
+
+extern "C" int dcvc_build_factorized_cdfs(const float *params, int32_t C, int32_t *cdf, int32_t *sizes, int32_t *offsets,
+                                          void *stream) {
+    if (!params || !cdf || !sizes || !offsets || C <= 0 || C > 256) return DCVC_E_ARG;
+    const size_t lds = (size_t)(2 * C + 4) * sizeof(int) + (size_t)C * kTabCols * sizeof(float);
+    static bool attr_ok = hipFuncSetAttribute((const void *)factorized_cdfs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                              160 * 1024) == hipSuccess;
+    if (!attr_ok && lds > 64 * 1024) return DCVC_E_LAUNCH;
+    hipLaunchKernelGGL(factorized_cdfs_kernel, dim3(1), dim3(256), lds, (hipStream_t)stream, params, C, cdf, sizes, offsets);
     RET_LAUNCH();
 }
 

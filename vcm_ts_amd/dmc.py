@@ -179,10 +179,18 @@ class CodecBase(nn.Module):
     _distribution = "laplace"
     _z_names = ("bit_estimator_z",)
 
-    def update(self, force=False):
+    def update(self, force=False, device_tables=False):
+        """CompressionModel.update (common_model.py:75-80): build the three CDF tables.  Default: on the host
+        with the reference's own fp32 arithmetic (integer-identical tables: interoperable streams).
+        device_tables=True: by the GPU kernels (dcvc_build_*_cdfs; an entry may differ by one count from the
+        reference's, so only for streams this library both writes and reads)."""
         if self.entropy_coder is not None and not force:
             return
         self.entropy_coder = E.EntropyCoder()
+        if device_tables:
+            self._tables = E.device_tables(self.engine(), self._distribution, {n: self._zblock(n) for n in self._z_names})
+            self._dcoder = None
+            return
         sd = {k: v for k, v in self._pmap.items()}
         t = {"scale": E.scale_table_cdfs(self._distribution)}
         for n in self._z_names:

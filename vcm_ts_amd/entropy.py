@@ -254,6 +254,39 @@ def factorized_cdfs(p):
     return cdf.numpy(), (lengths + 2).int().numpy(), (-lo).int().numpy()
 
 
+def device_tables(engine, distribution, z_blocks):
+    """The same tables built by the GPU kernels of include/dcvc_hip.h ("update(): ... on the device", opt-in;
+    SURVEY 8f-3): {"scale": (cdf, sizes, offsets), name: ...} as numpy int32 arrays shaped like the host
+    builders' (columns trimmed to the longest row + 2).  z_blocks: {name: (11, C) device parameter block}.
+    Device libm differs from torch-CPU's in the last ulp, so an entry on a rounding boundary may differ by one
+    count from the reference table: use for streams this library both writes and reads."""
+    import ctypes as C
+
+    L = engine.L
+    cols = int(L.dcvc_cdf_table_cols())
+    dev = engine.device
+
+    def fetch(rows, launch):
+        cdf = torch.zeros((rows, cols), dtype=torch.int32, device=dev)
+        sz = torch.zeros(rows, dtype=torch.int32, device=dev)
+        off = torch.zeros(rows, dtype=torch.int32, device=dev)
+        launch(cdf, sz, off)
+        sz_h = sz.cpu().numpy()
+        w = int(sz_h.max())
+        return np.ascontiguousarray(cdf[:, :w].cpu().numpy()), sz_h, off.cpu().numpy()
+
+    lmin, _ = scale_log_params(distribution)
+    table = torch.exp(torch.linspace(lmin, math.log(SCALE_MAX), SCALE_LEVELS)).to(dev)  # the 256 levels (:220-221)
+    out = {"scale": fetch(SCALE_LEVELS, lambda c, s, o: lib.check(
+        L.dcvc_build_scale_cdfs(table.data_ptr(), SCALE_LEVELS, 0 if distribution == "laplace" else 1, c.data_ptr(),
+                                s.data_ptr(), o.data_ptr(), engine.stream()), "build_scale_cdfs"))}
+    for name, blk in z_blocks.items():
+        out[name] = fetch(blk.shape[1], lambda c, s, o, blk=blk: lib.check(
+            L.dcvc_build_factorized_cdfs(blk.data_ptr(), blk.shape[1], c.data_ptr(), s.data_ptr(), o.data_ptr(),
+                                         engine.stream()), "build_factorized_cdfs"))
+    return out
+
+
 def factorized_params(sd, prefix):
     """Collect h/b/a of the four layers from a state dict with the reference's key names."""
     p = {}

@@ -233,10 +233,16 @@ class Tape:
         dflow = None if self.is_const(flow) else self.grad(flow)
         if dsrc is None and dflow is None:
             return
+        fix = None
+        if dsrc is not None:  # zeroed once; the kernels hand it back clean
+            n = src.N * src.H * src.W * src.C
+            fix = getattr(self.e, "_fix_scratch", None)  # lives with the engine: launches on one stream reuse it in order
+            if fix is None or fix.numel() < n:
+                fix = self.e._fix_scratch = torch.zeros(n, dtype=torch.int64, device=self.e.device)
         lib.check(self.L.dcvc_warp_bwd(src.ptr, src.cs, flow.ptr, flow.cs, dout.ptr, dout.cs,
                                        dsrc.ptr if dsrc else None, dsrc.cs if dsrc else 0,
                                        dflow.ptr if dflow else None, dflow.cs if dflow else 0, src.N, src.H, src.W,
-                                       src.C, self.stream()), "warp_bwd")
+                                       src.C, fix.data_ptr() if fix is not None else None, self.stream()), "warp_bwd")
 
     def _b_up2(self, src, out, scale, out2):
         if self.is_const(src):

@@ -80,16 +80,18 @@ class IntraNoAR(CodecBase):
         if self.entropy_coder is None:
             raise RuntimeError("call update() before compress()/decompress()")
         o = self._run(x, q_scale, "compress")
-        assert o["N"] == 1 and coder in ("host", "device")
+        N = o["N"]  # N > 1: a batch of rate points (one q-scale per element), one independent stream each
+        assert coder in ("host", "device")
         zs = o["z_hat"]
         pending = (self._stage_symbols if coder == "host" else self._stage_symbols_device)([  # image_model.py:168-171
-            ("bit_estimator_z", o["sym_z"], None, (1, self.N, zs.H, zs.W)),
+            ("bit_estimator_z", o["sym_z"], None, (N, self.N, zs.H, zs.W)),
             ("scale", o["r"]["sym"][0], o["r"]["idx"][0], None),
             ("scale", o["r"]["sym"][1], o["r"]["idx"][1], None),
-        ])
+        ], batch=N)
         if defer:
             return {"pending": pending, "x_hat": o["x_hat"].nchw(), "_views": o}
-        return {"bit_stream": pending.finish(), "x_hat": o["x_hat"].nchw(), "_views": o}
+        streams = pending.finish_all()
+        return {"bit_stream": streams[0], "bit_streams": streams, "x_hat": o["x_hat"].nchw(), "_views": o}
 
     @torch.no_grad()
     def decompress(self, bit_stream, height, width, q_scale, coder=None, defer_check=False):

@@ -160,6 +160,8 @@ _SIGS = {
     "dcvc_dual_prior_enc": [C.POINTER(DualPriorArgs), vp],
     "dcvc_dual_prior_dec_index": [C.POINTER(DualPriorArgs), vp],
     "dcvc_dual_prior_dec_apply": [C.POINTER(DualPriorArgs), vp],
+    "dcvc_build_scale_cdfs": [vp, i32, i32, vp, vp, vp, vp],
+    "dcvc_build_factorized_cdfs": [vp, i32, vp, vp, vp, vp],
     "dcvc_scale_bits": [vp, vp, vp, vp, i32, i32, i64, vp],
     "dcvc_factorized_bits": [vp, i32, vp, vp, vp, i32, i32, i32, vp],
     "dcvc_sq_err": [vp, i32, vp, i32, vp, vp, i32, i32, i32, vp],
@@ -170,7 +172,7 @@ _SIGS = {
     "dcvc_channel_dot": [vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, i32, vp],
     "dcvc_mask_accumulate": [vp, i32, vp, i32, f32, vp, i32, i64, i32, vp],
     "dcvc_add_planes": [vp, i32, vp, i32, vp, i32, i64, i32, vp],
-    "dcvc_warp_bwd": [vp, i32, vp, i32, vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, vp],
+    "dcvc_warp_bwd": [vp, i32, vp, i32, vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, vp, vp],
     "dcvc_up2_bwd": [vp, i32, vp, i32, i32, i32, i32, i32, f32, vp],
     "dcvc_down2_bwd": [vp, i32, vp, i32, i32, i32, i32, i32, f32, vp],
     "dcvc_maxpool2_bwd": [vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, vp],
@@ -188,7 +190,7 @@ _SIGS = {
     "dcvc_drans_build_lut": [vp, i32, i32, vp, vp],
 }
 
-HIP_SYMBOLS = sorted(list(_SIGS) + ["dcvc_conv_pack_size", "dcvc_conv_s16_pack_bytes", "dcvc_conv_chan_partial_parts", "dcvc_hip_version", "dcvc_conv_wgrad_scratch_min",
+HIP_SYMBOLS = sorted(list(_SIGS) + ["dcvc_cdf_table_cols", "dcvc_conv_pack_size", "dcvc_conv_s16_pack_bytes", "dcvc_conv_chan_partial_parts", "dcvc_hip_version", "dcvc_conv_wgrad_scratch_min",
                                     "dcvc_drans_default_lanes", "dcvc_drans_scratch_words"])
 RANS_SYMBOLS = [
     "dcvc_rans_encoder_create", "dcvc_rans_encoder_destroy", "dcvc_rans_encoder_reset",
@@ -208,6 +210,8 @@ def hip():
             fn.restype = C.c_int
         L.dcvc_conv_pack_size.argtypes = [i32, i32, i32, vp, C.POINTER(i32)]
         L.dcvc_conv_pack_size.restype = i64
+        L.dcvc_cdf_table_cols.argtypes = []
+        L.dcvc_cdf_table_cols.restype = i32
         L.dcvc_conv_chan_partial_parts.argtypes = [i32, i32, i32, i32]
         L.dcvc_conv_chan_partial_parts.restype = i32
         L.dcvc_conv_s16_pack_bytes.argtypes = [i32, i32, i32, vp, C.POINTER(i32)]
