@@ -87,20 +87,31 @@ __global__ void channel_finish(const float *__restrict__ scratch, float *__restr
     }
 }
 
-// the same finish over the partial rows a convolution's epilogue wrote (dcvc_conv_args.chan_partial)
-__global__ void channel_finish_rows(const float *__restrict__ part, int parts, int stride, float *__restrict__ mean,
-                                    int HW, int C) {
-    __shared__ float sm[256];
+// the same finish over the partial rows a convolution's epilogue wrote (dcvc_conv_args.chan_partial): a 1080p
+// layer leaves 8160 rows, so 64 row-lanes per channel with four independent accumulators each keep enough loads
+// in flight (16 row-lanes took 86 us); fixed assignment and fixed tree -> run-to-run identical
+__global__ __launch_bounds__(1024) void channel_finish_rows(const float *__restrict__ part, int parts, int stride,
+                                                            float *__restrict__ mean, int HW, int C) {
+    __shared__ float sm[1024];
     const int n = blockIdx.x, t = threadIdx.x;
-    const int c = blockIdx.y * 16 + (t & 15), lane16 = t >> 4;
-    float s = 0.f;
-    if (c < C)
-        for (int b = lane16; b < parts; b += 16) s += part[((size_t)n * parts + b) * stride + c];
-    sm[t] = s;
+    const int c = blockIdx.y * 16 + (t & 15), rl = t >> 4;  // 64 row-lanes
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (c < C) {
+        const float *p = part + (size_t)n * parts * stride + c;
+        int b = rl;
+        for (; b + 192 < parts; b += 256) {
+            s0 += p[(size_t)b * stride];
+            s1 += p[(size_t)(b + 64) * stride];
+            s2 += p[(size_t)(b + 128) * stride];
+            s3 += p[(size_t)(b + 192) * stride];
+        }
+        for (; b < parts; b += 64) s0 += p[(size_t)b * stride];
+    }
+    sm[t] = (s0 + s1) + (s2 + s3);
     __syncthreads();
     if (t < 16 && c < C) {
         float r = 0.f;
-        for (int k = 0; k < 16; ++k) r += sm[k * 16 + t];
+        for (int k = 0; k < 64; ++k) r += sm[k * 16 + t];
         mean[(size_t)n * C + c] = r / (float)HW;
     }
 }
@@ -465,7 +476,7 @@ extern "C" int dcvc_channel_mean(const float *src, int32_t src_cs, float *mean, 
 extern "C" int dcvc_channel_mean_finish(const float *chan_partial, int32_t parts, int32_t row_stride, float *mean, int32_t N,
                                         int32_t C, int32_t HW, void *stream) {
     if (!chan_partial || !mean || parts <= 0 || row_stride < C || N <= 0 || C <= 0 || HW <= 0) return DCVC_E_ARG;
-    hipLaunchKernelGGL(channel_finish_rows, dim3(N, (C + 15) / 16), dim3(256), 0, (hipStream_t)stream, chan_partial, parts,
+    hipLaunchKernelGGL(channel_finish_rows, dim3(N, (C + 15) / 16), dim3(1024), 0, (hipStream_t)stream, chan_partial, parts,
                        row_stride, mean, HW, C);
     RET_LAUNCH();
 }
