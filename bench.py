@@ -197,7 +197,9 @@ def train_workload(args, dev, rank, world):
     model = build_model(make_cfg(lambdas=(85.0, 170.0, 380.0, 840.0)), precision=prec).to(dev).train()
     model.activate_modules_all()
     net = model
-    if world > 1:
+    if torch.distributed.is_available() and torch.distributed.is_initialized():
+        # also with ONE rank under a launcher: DistributedDataParallel's bucketed all-reduce then runs over RCCL
+        # on the single GPU, the code path of trainer_multi.py at N > 1
         net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[dev.index] if args.dist_backend == "nccl" else None,
                                                         find_unused_parameters=True)
     opt = torch.optim.AdamW(net.parameters(), lr=1e-4)
@@ -233,7 +235,7 @@ def train_workload(args, dev, rank, world):
            "config": {"workload": "trainer.py / trainer_multi.py optimiser step (configs[2] at N=1, configs[3] at N>1): "
                                   "forward_one_frame + backward + AdamW, single mode, uniform-random clips, random-init weights",
                       "batch_per_gpu": batch, "global_batch": batch * world, "height": size, "width": size, "precision": prec,
-                      "parallelism": f"ddp x{world} ({args.dist_backend})" if world > 1 else "single GPU", "final_loss": round(loss, 4)},
+                      "parallelism": f"ddp x{world} ({args.dist_backend})" if net is not model else "single GPU", "final_loss": round(loss, 4)},
            "roofline": {"bound": "mfma", "kernel": "conv_mfma<3,1,*> forward + data-gradient launches of one step",
                         "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
                         "traffic": None, "launches": dom["launches"]}}
@@ -309,7 +311,11 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch one rank per GPU "
                          "(python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...) or let bench.py do it")
-    if world > 1:
+    # under a launcher (RANK set) the process group is created even for one rank: `torchrun --nproc-per-node 1
+    # bench.py --dist-backend nccl` then runs the RCCL communicator, barrier and MAX-reduction of the timed
+    # region on a single GPU, the same calls every rank makes at N > 1
+    grouped = world > 1 or "RANK" in os.environ
+    if grouped:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -323,7 +329,7 @@ def main():
         out = train_workload(args, dev, rank, world)
         if rank == 0:
             print(json.dumps(out))
-        if world > 1:
+        if grouped:
             dist.destroy_process_group()
         return
 
@@ -372,7 +378,7 @@ def main():
                           "bits_per_gop": int(bits)}}
         if rank == 0:
             print(json.dumps(out))
-        if world > 1:
+        if grouped:
             dist.destroy_process_group()
         return
 
@@ -534,9 +540,11 @@ def main():
                           "rans_payload_bytes": nbytes, "rans_symbols": int(sum(p[0].size for p in planes)),
                           "end_to_end_fps_all_cores": round(1.0 / (sec_all + t_enc), 5),
                           "end_to_end_fps_1_thread": round(1.0 / (sec_1 + t_enc), 6)}}
+    if grouped:
+        out["config"]["dist_backend"] = args.dist_backend
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if grouped:
         dist.destroy_process_group()
     if not parity_ok and not args.lenient_parity:
         sys.stderr.write("bench.py: the fp16x3 run is outside 1e-4 of the fp32 run (see parity_mode_fp32.fast_vs_fp32)\n")

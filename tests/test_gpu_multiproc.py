@@ -185,3 +185,29 @@ def test_bench_train_workload_with_world_size_two():
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 8 and line["value"] > 0
     assert np.isfinite(line["config"]["final_loss"])
+
+
+def test_bench_runs_over_rccl_with_one_rank():
+    """`--dist-backend nccl` (= RCCL on ROCm) on the one GPU of the test box: a launcher with ONE rank makes
+    bench.py create the RCCL communicator and run the barrier + MAX all-reduce of the timed region on the
+    device -- the calls every rank makes at N > 1 (two ranks cannot share one GPU under RCCL)."""
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr",
+                        "127.0.0.1", "--master-port", "29547", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1",
+                        "--warmup", "0", "--height", "128", "--width", "192", "--gop", "3", "--dist-backend", "nccl",
+                        "--no-cpu-baseline", "--no-parity-leg", "--no-extra-workloads"],
+                       env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 1 and d["config"]["dist_backend"] == "nccl" and d["value"] > 0
+
+
+def test_training_bench_runs_ddp_over_rccl_with_one_rank():
+    """The trainer step of bench.py --workload train under a one-rank launcher with the nccl (= RCCL) backend:
+    DistributedDataParallel buckets and all-reduces the 17.5 M gradient floats over RCCL on the GPU."""
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr",
+                        "127.0.0.1", "--master-port", "29548", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--workload", "train",
+                        "--steps", "2", "--warmup", "1", "--dist-backend", "nccl", "--no-cpu-baseline"],
+                       env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 1 and "ddp x1 (nccl)" in d["config"]["parallelism"] and d["value"] > 0

@@ -35,7 +35,7 @@ def timed_region(fn, device=None):
 
     import torch.distributed as dist
 
-    multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    multi = dist.is_available() and dist.is_initialized()  # also a one-rank group: same barrier + reduction path
 
     def fence():
         if multi:
