@@ -95,7 +95,8 @@ def _check_sequence(d, i, fx, xs, n_p, name, plane_bound, deep_tol=TOL):
         print(f"\n[{name} {d.engine().precision}] p{t} relative deviation from the reference: " +
               ", ".join(f"{k} {v:.1e}" for k, v in devs.items()))
         for k, v in devs.items():
-            assert v <= tol, (p + k, v, tol)
+            # the totals north_star names (bpp, distortion, PSNR) hold 1e-4 at every depth; `tol` is for the parts
+            assert v <= (TOL if k in ("bpp", "bit", "mse", "psnr") else tol), (p + k, v, tol)
         for k, v in dpb.items():
             # mean / std tightly; the abs-max is a single element and moves when one symbol rounds
             # the other way (summation-order noise of ~1e-7 is enough)
@@ -177,7 +178,8 @@ def test_bench_size_matches_reference_fixture(nets):
     xs = [pad_frame(torch.from_numpy(fr[t : t + 1])).cuda() for t in range(3)]
     assert xs[0].shape == (1, 3, 1088, 1920)
     # second P picture: at this size and rate (bpp ~6 with random-init weights, 1.4 M symbols per picture) the
-    # ties of the first two pictures move single rate components by up to ~3e-4; stated, not hidden
+    # ties of the first two pictures move single rate COMPONENTS by up to ~3e-4 (bpp_mv_y 2.4e-4 in the exact-fp32
+    # mode); total bpp, mse and PSNR stay within 1e-4 (asserted inside).  Stated, not hidden
     _check_sequence(d, i, fx, xs, 2, "seq_1088x1920", plane_bound=5e-3, deep_tol=5e-4)
     d.engine().release()
     i.engine().release()
