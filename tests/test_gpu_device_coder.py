@@ -215,3 +215,21 @@ def test_update_on_the_device_builds_the_reference_tables():
     c = d.compress(seq[1], dpb, 1.0, 1.0)
     r = d.decompress(dpb, c["bit_stream"], 128, 192, 1.0, 1.0)
     assert torch.equal(r["dpb"]["ref_frame"], c["dpb"]["ref_frame"])
+
+
+def test_device_coder_guards_its_two_payload_slots():
+    """Two payload buffers / pinned status words alternate: a third deferred picture before the first was
+    fetched would overwrite its bytes.  begin() must refuse instead, as the host path does."""
+    from vcm_ts_amd.intra import IntraNoAR
+
+    i = IntraNoAR().to(DEV).eval()
+    i.update()
+    x = torch.rand(1, 3, 64, 64, device=DEV)
+    a = i.compress(x, 1.0, defer=True, coder="device")
+    b = i.compress(x, 1.0, defer=True, coder="device")
+    with pytest.raises(RuntimeError, match="pending"):
+        i.compress(x, 1.0, defer=True, coder="device")
+    first = a["pending"].finish()
+    assert first == b["pending"].finish() and first[:4] == E.DRANS_MAGIC
+    c = i.compress(x, 1.0, defer=True, coder="device")  # the slot is free again
+    assert c["pending"].finish() == first
