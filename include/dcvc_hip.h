@@ -124,6 +124,17 @@ int dcvc_conv_pack_weights(const float *w, const float *b, int32_t Cout, int32_t
 
 int dcvc_conv2d(const dcvc_conv_args *a, void *stream);
 
+/* ---- layers with at most 16 output channels (DCVC_PREC_FP16X3 only) -------------------------------------
+ * SpyNet's 32->16 and 16->2 7x7 layers, the 64->3 reconstruction layer (video_net.py:99-115,
+ * video_model.py:115-128): 16-pixel x 16-channel tiles on v_mfma_f32_16x16x32_f16 whose 32-deep K carries the
+ * hi/lo operand split (vcm_ts_amd/csrc/conv_small.hip), instead of padding the channels to 32.  Same
+ * dcvc_conv_args, restricted to ks 3 or 7, stride 1, no pixel shuffle / gate / res2 / chan_partial; weights
+ * from dcvc_conv_small_pack_weights (HOST; DCVC_E_RANGE as dcvc_conv_s16_pack_weights). */
+int64_t dcvc_conv_small_pack_bytes(int32_t Cout, int32_t ks, int32_t nseg, const int32_t *seg_C);
+int dcvc_conv_small_pack_weights(const float *w, const float *b, int32_t Cout, int32_t ks, int32_t nseg,
+                                 const int32_t *seg_C, void *wpack, float *bpack);
+int dcvc_conv2d_small(const dcvc_conv_args *a, void *stream);
+
 /* ---- pre-split activations ("S16") --------------------------------------------------------
  * The fast form of DCVC_PREC_FP16X3 for 3x3 stride-1 layers whose inputs were produced by another
  * convolution (vcm_ts_amd/csrc/conv_s16.hip).  An S16 tensor of C channels (C % 16 == 0) is PLANAR in

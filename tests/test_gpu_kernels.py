@@ -94,6 +94,60 @@ def test_split_fp16_conv_matches_fp64(eng_split, case):
     assert (got - want).abs().max().item() < 3e-6 * scale + 2e-7 * want.abs().max().item()
 
 
+SMALL_CASES = [
+    # cin segments, cout, ks, H, W, N, in_slope, out_slope, residual
+    ((32,), 16, 7, 40, 72, 1, None, 0.0, False),       # SpyNet conv4
+    ((16,), 2, 7, 33, 45, 2, None, None, True),        # SpyNet conv5 + flow residual, ragged tiles, two images
+    ((64,), 3, 3, 32, 96, 1, None, "clamp01", False),  # recon_conv
+    ((24,), 8, 3, 17, 31, 1, 0.1, 0.01, True),         # chunk tail (24 = 16 + 8), activation on load
+    ((16, 32), 12, 7, 9, 33, 1, None, 0.2, False),     # two segments
+    ((3,), 16, 3, 64, 64, 1, None, None, False),       # 3-channel picture input
+]
+
+
+@pytest.mark.parametrize("case", SMALL_CASES, ids=[f"m{i}" for i in range(len(SMALL_CASES))])
+def test_small_cout_conv_matches_fp64_and_the_32_column_kernel(eng_split, case):
+    """dcvc_conv2d_small (<= 16 output channels: 16x16x32 MFMA whose K carries the hi/lo split, conv_small.hip)
+    against an fp64 reference within the split-fp16 error bound of test_split_fp16_conv_matches_fp64, and against
+    conv_mfma on the same layer (same operand values, other accumulation order: fp32 rounding apart)."""
+    segs, cout, ks, H, W, N, in_slope, out_slope, use_res = case
+    eng = eng_split
+    g = torch.Generator().manual_seed(SMALL_CASES.index(case) + 40)
+    cin = sum(segs)
+    mag = torch.tensor([1e-3, 1.0, 20.0])[torch.randint(0, 3, (N, cin, 1, 1), generator=g)]
+    x = torch.randn(N, cin, H, W, generator=g) * mag
+    w = torch.randn(cout, cin, ks, ks, generator=g) / math.sqrt(cin * ks * ks)
+    b = torch.randn(cout, generator=g) * 0.1
+    xin = x.double() if in_slope is None else F.leaky_relu(x.double(), in_slope)
+    want = F.conv2d(xin, w.double(), b.double(), padding=ks // 2)
+    scale = F.conv2d(xin.abs(), w.double().abs(), None, padding=ks // 2).max().item()
+    if out_slope == "clamp01":
+        want = want.clamp(0, 1)
+    elif out_slope is not None:
+        want = F.leaky_relu(want, out_slope)
+    res = None
+    if use_res:
+        r = torch.randn(want.shape, generator=g)
+        want = want + r.double()
+        res = to_view(eng, "sm/res", r)
+    pk = eng.pack(("small", case), torch.nn.Parameter(w.cuda()), torch.nn.Parameter(b.cuda()), segs, False)
+    views, c0 = [], 0
+    for i, c in enumerate(segs):
+        views.append(to_view(eng, f"sm/in{i}", x[:, c0 : c0 + c]))
+        c0 += c
+    outs = {}
+    for small in (True, False):
+        eng.use_small = small
+        out = eng.buf(f"sm/out{int(small)}", N, H, W, cout)
+        out.base.fill_(float("nan"))
+        assert eng.small_capable(pk, 1, None, None, None) == small
+        eng.conv(pk, views, out, in_slope=in_slope, out_slope=out_slope, res=res)
+        outs[small] = eng.to_nchw(out).cpu().double()
+    eng.use_small = True
+    assert (outs[True] - want).abs().max().item() < 3e-6 * scale + 2e-7 * want.abs().max().item()
+    assert (outs[True] - outs[False]).abs().max().item() < 2e-6 * scale + 2e-7 * want.abs().max().item()
+
+
 S16_CASES = [
     # cin segments, cout, H, W, N, ps, in_slope, out_slope, res ("f32"/"s16"/None), gate, res2, twin act ("none" = no twin), f32 out
     ((64,), 64, 40, 72, 1, False, None, 0.01, "f32", False, None, "none", True),      # partial tiles in both directions

@@ -92,7 +92,7 @@ class View:
 
 class PackedConv:
     __slots__ = ("w", "b", "ks", "Cout", "Cout_pad", "seg_C", "ps", "version", "precision", "weight", "bias",
-                 "cin_slice", "key", "s16")
+                 "cin_slice", "key", "s16", "small")
 
 
 class Engine:
@@ -115,6 +115,7 @@ class Engine:
         self._edges = {}     # distribution -> device (256,) fp32 bin edges of build_indexes
         self._status = None  # device status word of the split-fp16 kernels (saturation flag)
         self.use_s16 = os.environ.get("DCVC_S16", "1") != "0"
+        self.use_small = os.environ.get("DCVC_SMALL", "1") != "0"   # dcvc_conv2d_small for <= 16 output channels
         # fp16x3 mode clamps |activation| > 8188 on load; with range_check on, every convolution launch also
         # flags outputs beyond that magnitude in the status word (check_status() raises).  Off by default: it
         # costs VALU work in the epilogue; bench.py and the tests turn it on for a checked pass.
@@ -357,6 +358,36 @@ class Engine:
         pk.s16 = q
         return q
 
+    def pack_small(self, pk: PackedConv) -> PackedConv:
+        """The same layer packed for dcvc_conv2d_small (<= 16 output channels), cached beside the other packing."""
+        q = getattr(pk, "small", None)
+        if q is not None and q.version == pk.version:
+            return q
+        w = pk.weight.detach().float().cpu()
+        if pk.cin_slice is not None:
+            w = w[:, pk.cin_slice[0] : pk.cin_slice[1]]
+        w = w.contiguous().numpy()
+        b = None if pk.bias is None else pk.bias.detach().float().cpu().contiguous().numpy()
+        segs = (C.c_int32 * len(pk.seg_C))(*pk.seg_C)
+        n = self.L.dcvc_conv_small_pack_bytes(pk.Cout, pk.ks, len(pk.seg_C), segs)
+        if n < 0:
+            raise lib.KernelError(f"conv_small_pack_bytes({pk.key})")
+        wp = np.empty(n // 4, np.float32)
+        bp = np.empty(16, np.float32)
+        lib.check(self.L.dcvc_conv_small_pack_weights(w.ctypes.data, None if b is None else b.ctypes.data, pk.Cout, pk.ks,
+                                                      len(pk.seg_C), segs, wp.ctypes.data, bp.ctypes.data),
+                  f"conv_small_pack_weights({pk.key}) [status -3: a |weight| >= 1023.5 does not fit split fp16, use precision='fp32']")
+        q = PackedConv()
+        q.w, q.b = torch.from_numpy(wp).to(self.device), torch.from_numpy(bp).to(self.device)
+        q.ks, q.Cout, q.Cout_pad, q.seg_C, q.ps, q.version, q.key = pk.ks, pk.Cout, 16, pk.seg_C, False, pk.version, pk.key
+        pk.small = q
+        return q
+
+    def small_capable(self, pk: PackedConv, stride, gate, res2, chan_partial) -> bool:
+        """Layers dcvc_conv2d_small covers: <= 16 output channels, 3x3 / 7x7, stride 1, plain epilogue, fp16x3."""
+        return (self.precision == "fp16x3" and self.tape is None and self.use_small and pk.Cout <= 16 and pk.ks in (3, 7)
+                and stride == 1 and not pk.ps and gate is None and res2 is None and chan_partial is None)
+
     def s16_capable(self, pk: PackedConv, stride=1) -> bool:
         """Layer geometry dcvc_conv2d_s16 covers (3x3, stride 1, 16-channel granularity)."""
         cfin = pk.Cout // 4 if pk.ps else pk.Cout
@@ -455,8 +486,10 @@ class Engine:
             a.seg[i].ptr, a.seg[i].C, a.seg[i].cs = s.ptr, s.C, s.cs
         a.nseg, a.N, a.Hin, a.Win = len(srcs), s0.N, s0.H, s0.W
         a.in_act, a.in_slope = (0, 0.0) if in_slope is None else (1, in_slope)
-        a.wpack, a.bpack = pk.w.data_ptr(), pk.b.data_ptr()
-        a.ks, a.stride, a.Cout, a.Cout_pad = pk.ks, stride, pk.Cout, pk.Cout_pad
+        small = self.small_capable(pk, stride, gate, res2, chan_partial)
+        wq = self.pack_small(pk) if small else pk
+        a.wpack, a.bpack = wq.w.data_ptr(), wq.b.data_ptr()
+        a.ks, a.stride, a.Cout, a.Cout_pad = pk.ks, stride, pk.Cout, wq.Cout_pad
         pad = pk.ks // 2
         Ho = (s0.H + 2 * pad - pk.ks) // stride + 1
         Wo = (s0.W + 2 * pad - pk.ks) // stride + 1
@@ -479,8 +512,9 @@ class Engine:
             a.status = self.status_word().data_ptr()
         if chan_partial is not None:
             a.chan_partial = chan_partial.data_ptr()
-        self._launch_conv(lambda: lib.check(self.L.dcvc_conv2d(C.byref(a), self.stream()), "conv2d"), pk, s0, Ho, Wo, stride,
-                          res, res2)
+        fn, what = (self.L.dcvc_conv2d_small, "conv2d_small") if small else (self.L.dcvc_conv2d, "conv2d")
+        self._launch_conv(lambda: lib.check(fn(C.byref(a), self.stream()), what), pk, s0, Ho, Wo, stride, res, res2,
+                          "small" if small else "")
         self.calls += 1
         self._rec("conv", pk, tuple(srcs), out, stride, in_slope, out_slope, res, gate, res2)
         return out

@@ -139,6 +139,8 @@ i32, i64, f32, vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
 _SIGS = {
     "dcvc_conv2d": [C.POINTER(ConvArgs), vp],
     "dcvc_conv_pack_weights": [vp, vp, i32, i32, i32, vp, i32, i32, vp, vp],
+    "dcvc_conv2d_small": [C.POINTER(ConvArgs), vp],
+    "dcvc_conv_small_pack_weights": [vp, vp, i32, i32, i32, vp, vp, vp],
     "dcvc_conv2d_s16": [C.POINTER(ConvS16Args), vp],
     "dcvc_conv_s16_pack_weights": [vp, vp, i32, i32, i32, vp, i32, vp, vp],
     "dcvc_s16_pack": [vp, i32, vp, i32, i32, i64, i32, i32, f32, vp, vp],
@@ -190,7 +192,7 @@ _SIGS = {
     "dcvc_drans_build_lut": [vp, i32, i32, vp, vp],
 }
 
-HIP_SYMBOLS = sorted(list(_SIGS) + ["dcvc_cdf_table_cols", "dcvc_conv_pack_size", "dcvc_conv_s16_pack_bytes", "dcvc_conv_chan_partial_parts", "dcvc_hip_version", "dcvc_conv_wgrad_scratch_min",
+HIP_SYMBOLS = sorted(list(_SIGS) + ["dcvc_cdf_table_cols", "dcvc_conv_pack_size", "dcvc_conv_small_pack_bytes", "dcvc_conv_s16_pack_bytes", "dcvc_conv_chan_partial_parts", "dcvc_hip_version", "dcvc_conv_wgrad_scratch_min",
                                     "dcvc_drans_default_lanes", "dcvc_drans_scratch_words"])
 RANS_SYMBOLS = [
     "dcvc_rans_encoder_create", "dcvc_rans_encoder_destroy", "dcvc_rans_encoder_reset",
@@ -214,6 +216,8 @@ def hip():
         L.dcvc_cdf_table_cols.restype = i32
         L.dcvc_conv_chan_partial_parts.argtypes = [i32, i32, i32, i32]
         L.dcvc_conv_chan_partial_parts.restype = i32
+        L.dcvc_conv_small_pack_bytes.argtypes = [i32, i32, i32, vp]
+        L.dcvc_conv_small_pack_bytes.restype = i64
         L.dcvc_conv_s16_pack_bytes.argtypes = [i32, i32, i32, vp, C.POINTER(i32)]
         L.dcvc_conv_s16_pack_bytes.restype = i64
         L.dcvc_hip_version.restype = C.c_char_p
