@@ -92,7 +92,7 @@ class View:
 
 class PackedConv:
     __slots__ = ("w", "b", "ks", "Cout", "Cout_pad", "seg_C", "ps", "version", "precision", "weight", "bias",
-                 "cin_slice", "key", "s16", "small")
+                 "cin_slice", "key", "s16", "small", "host")
 
 
 class Engine:
@@ -329,6 +329,7 @@ class Engine:
         pk.ks, pk.Cout, pk.Cout_pad, pk.seg_C, pk.ps, pk.version = ks, Cout, cpad.value, tuple(seg_C), bool(ps), ver
         pk.precision = lib.PRECISIONS[self.precision]
         pk.weight, pk.bias, pk.cin_slice, pk.key = weight, bias, cin_slice, key
+        pk.host = True  # packed from the module's own weight: the alternative kernels may re-pack it their way
         self.packs[key] = pk
         return pk
 
@@ -385,13 +386,15 @@ class Engine:
 
     def small_capable(self, pk: PackedConv, stride, gate, res2, chan_partial) -> bool:
         """Layers dcvc_conv2d_small covers: <= 16 output channels, 3x3 / 7x7, stride 1, plain epilogue, fp16x3."""
-        return (self.precision == "fp16x3" and self.tape is None and self.use_small and pk.Cout <= 16 and pk.ks in (3, 7)
+        return (self.precision == "fp16x3" and self.tape is None and self.use_small and getattr(pk, "host", False)
+                and pk.Cout <= 16 and pk.ks in (3, 7)
                 and stride == 1 and not pk.ps and gate is None and res2 is None and chan_partial is None)
 
     def s16_capable(self, pk: PackedConv, stride=1) -> bool:
         """Layer geometry dcvc_conv2d_s16 covers (3x3, stride 1, 16-channel granularity)."""
         cfin = pk.Cout // 4 if pk.ps else pk.Cout
-        return (self.s16_enabled() and pk.ks == 3 and stride == 1 and pk.Cout % 16 == 0 and cfin % 16 == 0
+        return (self.s16_enabled() and getattr(pk, "host", False) and pk.ks == 3 and stride == 1 and pk.Cout % 16 == 0
+                and cfin % 16 == 0
                 and all(c % 16 == 0 for c in pk.seg_C))
 
     def conv(self, pk: PackedConv, srcs, out: View, stride=1, in_slope=None, out_slope=None, res: View = None,
