@@ -37,14 +37,17 @@ def crop(t):
     return t.detach()[..., :8, :8].contiguous().numpy().astype(np.float32)
 
 
-def build_nets():
+def build_nets(seed=0, gain=None):
+    """seed / gain select another set of name-seeded weights (params.seeded_state_dict): parity must not hinge on
+    one particular weight set."""
     DMC, IntraNoAR = load(with_cxx=True)
     torch.manual_seed(0)
+    kw = {"seed": seed} if gain is None else {"seed": seed, "gain": gain}
     d = DMC(anchor_num=4)
-    d.load_state_dict(seeded_state_dict(dmc_spec()))
+    d.load_state_dict(seeded_state_dict(dmc_spec(), **kw))
     d.eval()
     i = IntraNoAR()
-    i.load_state_dict(seeded_state_dict(intra_spec()))
+    i.load_state_dict(seeded_state_dict(intra_spec(), **kw))
     i.eval()
     return d, i
 
@@ -227,7 +230,18 @@ def stream_case():
     print("stream done")
 
 
+def second_weight_set():
+    """seq_128x192_w5.npz: I + 2 P pictures with a different weight set (seed 5, gain 1.2: lower rate)."""
+    d, i = build_nets(seed=5, gain=1.2)
+    dtap = Tap(d, ["optic_flow", "mv_decoder", "context_fusion_net", "contextual_decoder", "mv_hyper_prior_encoder", "contextual_hyper_prior_encoder"])
+    itap = Tap(i, ["hyper_enc"])
+    sequence_case(d, i, dtap, itap, "seq_128x192_w5", 128, 192, 2, seed=6)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "w5":
+        torch.set_num_threads(8)
+        return second_weight_set()
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     d, i = build_nets()

@@ -164,6 +164,24 @@ def test_estimate_path_matches_reference_fixtures(nets, name, h, w, n_p, seed):
     _check_sequence(d, i, golden(name), xs, n_p, name, plane_bound=2e-3)
 
 
+@pytest.mark.parametrize("precision", ["fp32", "fp16x3"])
+def test_second_weight_set_matches_reference_fixture(precision):
+    """tests/golden/seq_128x192_w5.npz: the reference run with ANOTHER weight set (seed 5, gain 1.2; P pictures at
+    0.3-0.4 bpp instead of 4-7): scalars at 1e-4, planes counted, in both arithmetic modes."""
+    from vcm_ts_amd.dmc import DMC
+    from vcm_ts_amd.intra import IntraNoAR
+
+    dev = torch.device("cuda:0")
+    d, i = DMC(precision=precision).to(dev).eval(), IntraNoAR(precision=precision).to(dev).eval()
+    d.load_state_dict(oracle_weights("dmc", 5, 1.2))
+    i.load_state_dict(oracle_weights("intra", 5, 1.2))
+    d.update(force=True)
+    i.update(force=True)
+    fr = frames(6, 3, 128, 192)
+    xs = [torch.from_numpy(fr[t : t + 1]).cuda() for t in range(3)]
+    _check_sequence(d, i, golden("seq_128x192_w5"), xs, 2, "seq_128x192_w5", plane_bound=2e-3)
+
+
 def test_bench_size_matches_reference_fixture(nets):
     """BASELINE configs[1]'s picture size, 1920x1080 zero-padded to 1088x1920 (video_coder.py:111-117),
     I + 2 P pictures against tests/golden/seq_1088x1920.npz, which make_golden_1080p.py produced by

@@ -39,10 +39,11 @@ dist.destroy_process_group()
 """
 
 
-def _run(args, env):
+def _run(args, env, nproc=2):
     e = dict(os.environ, **env)
-    return subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
-                           "127.0.0.1", "--master-port", "29541"] + args, env=e, capture_output=True, text=True, timeout=600)
+    return subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}",
+                           "--master-addr", "127.0.0.1", "--master-port", "29541"] + args, env=e, capture_output=True,
+                          text=True, timeout=900)
 
 
 def test_two_ranks_encode_disjoint_gops(tmp_path):
@@ -137,22 +138,28 @@ dist.destroy_process_group()
 """
 
 
-def test_ddp_training_step_averages_gradients_across_ranks(tmp_path):
-    """trainer_multi.py's step with the model wrapped in DistributedDataParallel: after
-    backward every rank holds the mean of the per-rank gradients, and parameters stay identical."""
+@pytest.mark.parametrize("world", [2, 4])
+def test_ddp_training_step_averages_gradients_across_ranks(tmp_path, world):
+    """trainer_multi.py's step with the model wrapped in DistributedDataParallel: after backward every rank holds
+    the mean of the per-rank gradients, and parameters stay identical.  world 4 rehearses BASELINE configs[3]
+    beyond two ranks (gloo rendezvous: all ranks share the one GPU of the test box)."""
     import pickle
 
     script = os.path.join(tmp_path, "ddp_worker.py")
     open(script, "w").write(DDP_WORKER)
     out = os.path.join(tmp_path, "ddp.pkl")
-    r = _run([script], {"DCVC_ROOT": ROOT, "DCVC_OUT": out})
+    r = _run([script], {"DCVC_ROOT": ROOT, "DCVC_OUT": out}, nproc=world)
     assert r.returncode == 0, r.stderr[-3000:]
-    (g0, p0), (g1, p1) = pickle.load(open(out, "rb"))
-    assert set(g0) == set(g1) and "feature_adaptor_I.weight" in g0 and "feature_adaptor_P.weight" not in g0
-    for k in g0:
-        assert torch.equal(g0[k], g1[k]), k                    # all-reduced: identical on both ranks
-    for k in p0:
-        assert torch.isfinite(p0[k]).all() and torch.equal(p0[k], p1[k]), k   # so are the parameters after two steps
+    gathered = pickle.load(open(out, "rb"))
+    assert len(gathered) == world
+    (g0, p0) = gathered[0]
+    assert "feature_adaptor_I.weight" in g0 and "feature_adaptor_P.weight" not in g0
+    for g1, p1 in gathered[1:]:
+        assert set(g0) == set(g1)
+        for k in g0:
+            assert torch.equal(g0[k], g1[k]), k                    # all-reduced: identical on every rank
+        for k in p0:
+            assert torch.isfinite(p0[k]).all() and torch.equal(p0[k], p1[k]), k   # so are the parameters after two steps
     # the all-reduced gradient is the mean of what each rank computes alone
     from vcm_ts_amd.dcvc_hem import build_model, make_cfg
     from vcm_ts_amd.synthetic import frames
@@ -164,7 +171,7 @@ def test_ddp_training_step_averages_gradients_across_ranks(tmp_path):
     model.dmc._noise_override = {"y": torch.rand(2, 96, 4, 4, generator=g) - 0.5, "mv_y": torch.rand(2, 64, 4, 4, generator=g) - 0.5,
                                  "z": torch.rand(2, 64, 1, 1, generator=g) - 0.5, "mv_z": torch.rand(2, 64, 1, 1, generator=g) - 0.5}
     acc = {}
-    for rank in (0, 1):
+    for rank in range(world):
         x = torch.from_numpy(np.stack([frames(70 + 10 * rank + i, 3, 64, 64) for i in range(2)])).to(dev)
         model.zero_grad(set_to_none=True)
         dpb = {"ref_frame": x[:, 0], "ref_feature": None, "ref_y": None, "ref_mv_y": None}
@@ -172,7 +179,7 @@ def test_ddp_training_step_averages_gradients_across_ranks(tmp_path):
         res["loss_to_opt"].backward()
         for k, v in model.dmc.named_parameters():
             if v.grad is not None:
-                acc[k] = acc.get(k, 0) + v.grad.detach().cpu() / 2
+                acc[k] = acc.get(k, 0) + v.grad.detach().cpu() / world
     assert set(acc) == set(g0)
     for k in acc:
         torch.testing.assert_close(g0[k], acc[k], rtol=1e-4, atol=1e-6 + 1e-5 * float(acc[k].abs().max()), msg=k)

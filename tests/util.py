@@ -15,10 +15,13 @@ from vcm_ts_amd.params import dmc_spec, intra_spec, seeded_state_dict  # noqa: E
 _W = {}
 
 
-def oracle_weights(kind):
-    if kind not in _W:
-        _W[kind] = seeded_state_dict(dmc_spec() if kind == "dmc" else intra_spec())
-    return _W[kind]
+def oracle_weights(kind, seed=0, gain=None):
+    """Name-seeded weights; (seed 5, gain 1.2) is the second weight set of tests/golden/seq_128x192_w5.npz."""
+    key = (kind, seed, gain)
+    if key not in _W:
+        kw = {"seed": seed} if gain is None else {"seed": seed, "gain": gain}
+        _W[key] = seeded_state_dict(dmc_spec() if kind == "dmc" else intra_spec(), **kw)
+    return _W[key]
 
 
 def golden(name):
