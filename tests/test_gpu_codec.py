@@ -608,3 +608,32 @@ def test_config_c5_four_rate_points_at_bench_size(nets):
     d.engine().release()
     i.engine().release()
     torch.cuda.empty_cache()
+
+
+def test_fast_mode_stays_within_tolerance_of_fp32_on_bench_content():
+    """What bench.py prints as parity_mode_fp32.fast_vs_fp32, asserted: a GOP of the bench's own synthetic
+    1080p content coded in split-fp16 mode and in exact-fp32 mode -- bits and GOP-mean PSNR within 1e-4
+    (north_star's tolerance), no convolution output beyond the split-fp16 range (status word 0)."""
+    from bench import GopQuality, synth_sequence
+    from vcm_ts_amd.dmc import DMC
+    from vcm_ts_amd.intra import IntraNoAR
+    from vcm_ts_amd.pipeline import GopEncoder, pad_frame
+
+    dev = torch.device("cuda:0")
+    seq = [pad_frame(f) for f in synth_sequence(dev, 8, 1080, 1920, seed=0)]
+    res = {}
+    for prec in ("fp16x3", "fp32"):
+        i, d = IntraNoAR(precision=prec).to(dev).eval(), DMC(precision=prec).to(dev).eval()
+        i.engine().range_check = d.engine().range_check = True
+        q = GopQuality(seq, 1080, 1920)
+        _, bits, _ = GopEncoder(i, d, gop_size=8).encode_gop(seq, 1.0, 1.0, 1.0, on_recon=q)
+        res[prec] = (bits, q.psnr(), i.engine().read_status() | d.engine().read_status())
+        i.engine().release()
+        d.engine().release()
+        del i, d
+        torch.cuda.empty_cache()
+    (bf, pf, sf), (b32, p32, _) = res["fp16x3"], res["fp32"]
+    assert sf == 0
+    assert abs(bf - b32) <= 1e-4 * b32, (bf, b32)
+    assert abs(pf.mean() - p32.mean()) <= 1e-4 * max(abs(p32.mean()), 1.0), (pf.mean(), p32.mean())
+    assert np.abs(pf - p32).max() < 5e-3  # per picture, in dB
