@@ -277,3 +277,21 @@ def test_device_format_oracle_round_trip_and_lane_streams(laplace_tables):
     assert end == 4 + len(sec)
     for m in (1, 63, 512, 513, 32640, 391680, 10**7):
         assert D.default_lanes(m) == lib.hip().dcvc_drans_default_lanes(m), m
+
+
+def test_index_bin_edges_reproduce_build_indexes():
+    """entropy.scale_index_edges (the 255 fp32 bin edges the kernels count instead of taking a logarithm):
+    counting edges <= s reproduces the reference's build_indexes on its own sweep (tables.npz), on every float
+    within 3 ulp of every edge and on 2 M random scales -- on the CPU, the same search the kernels perform."""
+    t = golden("tables")
+    s = torch.from_numpy(t["idx_sweep_in"])
+    for dist, key in (("laplace", "idx_sweep_laplace"), ("gaussian", "idx_sweep_gauss")):
+        edges = E.scale_index_edges(dist)
+        assert edges.shape == (256,) and torch.isinf(edges[-1]) and bool((edges[1:] > edges[:-1]).all())
+        count = lambda v: (edges[None, :] <= v[:, None]).sum(1).int()
+        np.testing.assert_array_equal(count(s).numpy(), t[key])
+        eb = edges[:-1].view(torch.int32)
+        near = torch.cat([(eb + d).view(torch.float32) for d in range(-3, 4)])
+        assert torch.equal(count(near), E.reference_scale_indexes(near.clone(), dist))
+        rnd = torch.exp(torch.empty(2_000_000).uniform_(-13.0, 6.0, generator=torch.Generator().manual_seed(1)))
+        assert torch.equal(torch.searchsorted(edges, rnd, right=True).int(), E.reference_scale_indexes(rnd.clone(), dist))
