@@ -294,6 +294,84 @@ def test_conv_matches_torch(eng, case):
     assert rel_err(got, want) < 2e-5
 
 
+def _sweep_cases(n, seed):
+    """Seeded random layer signatures: ragged pictures (down to 1 pixel), channel counts that are not multiples of
+    4 / 16 / 32, up to three input segments, every epilogue combination the C ABI accepts."""
+    rng = np.random.RandomState(seed)
+    out = []
+    while len(out) < n:
+        ks = int(rng.choice([1, 3, 3, 3, 7]))
+        stride = int(rng.choice([1, 1, 2])) if ks != 7 else 1
+        nseg = int(rng.choice([1, 1, 2, 3]))
+        segs = tuple(int(rng.choice([1, 2, 3, 5, 8, 12, 16, 24, 31, 32, 48, 64, 96, 130])) for _ in range(nseg))
+        ps = bool(rng.rand() < 0.2)
+        cout = int(rng.choice([1, 2, 3, 4, 8, 12, 16, 17, 32, 40, 64, 96, 128, 200]))
+        if ps:
+            cout = max(4, cout // 4 * 4)
+        if ks == 7 and sum(segs) * cout > 64 * 64:
+            continue  # keep the CPU reference quick
+        H, W = int(rng.randint(1, 70)), int(rng.randint(1, 70))
+        use_res = bool(rng.rand() < 0.5)
+        out.append((segs, cout, ks, stride, H, W, ps, [None, 0.1][rng.randint(2)],
+                    [None, 0.0, 0.01, "clamp01"][rng.randint(4)], use_res, use_res and bool(rng.rand() < 0.3),
+                    bool(rng.rand() < 0.25), int(rng.randint(1, 4))))
+    return out
+
+
+@pytest.mark.parametrize("precision", ["fp32", "fp16x3"])
+def test_conv_random_signature_sweep(eng, eng_split, precision):
+    """48 seeded random signatures per precision through Engine.conv (so the small-Cout and the 32/64-column kernels
+    are chosen as in the product) against an fp64 F.conv2d: fp32 mode within 1e-6, fast mode within 3e-6 of the
+    accumulated magnitude (the bounds of the fixed cases above)."""
+    e = eng if precision == "fp32" else eng_split
+    tol = 1e-6 if precision == "fp32" else 3e-6
+    for k, case in enumerate(_sweep_cases(48, 2024)):
+        segs, cout, ks, stride, H, W, ps, in_slope, out_slope, use_res, use_gate, use_res2, N = case
+        g = torch.Generator().manual_seed(1000 + k)
+        cin = sum(segs)
+        xs = [torch.randn(N, c, H, W, generator=g) for c in segs]
+        w = torch.randn(cout, cin, ks, ks, generator=g) / math.sqrt(cin * ks * ks)
+        b = torch.randn(cout, generator=g) * 0.1
+        x = torch.cat(xs, 1).double()
+        xin = x if in_slope is None else F.leaky_relu(x, in_slope)
+        want = F.conv2d(xin, w.double(), b.double(), stride=stride, padding=ks // 2)
+        scale = F.conv2d(xin.abs(), w.double().abs(), None, stride=stride, padding=ks // 2).max().item() + 1.0
+        if out_slope == "clamp01":
+            want = want.clamp(0, 1)
+        elif out_slope is not None:
+            want = F.leaky_relu(want, out_slope) if out_slope > 0 else F.relu(want)
+        if ps:
+            want = F.pixel_shuffle(want, 2)
+        res = gate = res2 = None
+        if use_res:
+            res = torch.randn(want.shape, generator=g)
+            r = res.double()
+            if use_gate:
+                gate = torch.rand(N, want.shape[1], generator=g)
+                r = r * gate.double()[:, :, None, None]
+            want = want + r
+        if use_res2:
+            res2 = torch.randn(want.shape, generator=g)
+            want = want + res2.double()
+        pk = e.pack(("sweep", precision, k), torch.nn.Parameter(w.cuda()), torch.nn.Parameter(b.cuda()), segs, ps)
+        views = []
+        for i, (xx, c) in enumerate(zip(xs, segs)):
+            wide = e.buf(f"sw/in{i}", N, H, W, c + 8)
+            views.append(e.from_nchw(xx.cuda(), wide.slice(4, c)))
+        full = e.buf("sw/out", N, want.shape[2], want.shape[3], want.shape[1] + 4)
+        full.base.fill_(float("nan"))
+        out = full.slice(4, want.shape[1])
+        rv = to_view(e, "sw/res", res) if res is not None else None
+        r2 = to_view(e, "sw/res2", res2) if res2 is not None else None
+        gt = gate.cuda().contiguous() if gate is not None else None
+        e.conv(pk, views, out, stride=stride, in_slope=in_slope, out_slope=out_slope, res=rv, gate=gt, res2=r2)
+        got = e.to_nchw(out).cpu().double()
+        assert got.shape == want.shape, case
+        err = (got - want).abs().max().item()
+        assert err < tol * scale + 2e-7 * want.abs().max().item(), (k, case, err, scale)
+    e.check_status()
+
+
 def test_conv_rejects_bad_arguments(eng):
     from vcm_ts_amd import lib
 

@@ -2,7 +2,7 @@
 the layer qualifies, the pre-split kernel (dcvc_conv2d_s16) in its output / residual formats, interleaved in one
 process (rounds of 10 launches each, median per variant).  --ablate adds the probe builds of
 tools/probes/conv_s16_probe.hip (no DMA / no MFMA / no epilogue) for the all-s16 variant.
-usage: conv_probe.py cin cout ks precision [H W] [--ablate]      cin may be "32,64" for several segments"""
+usage: conv_probe.py cin cout ks precision [H W] [--ablate] [--stride=2]      cin may be "32,64" for several segments"""
 import ctypes as C, os, sys
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -11,6 +11,7 @@ from vcm_ts_amd import lib
 from vcm_ts_amd.engine import Engine, View
 argv = [a for a in sys.argv[1:] if not a.startswith("--")]
 ablate = "--ablate" in sys.argv
+stride = next((int(a.split("=")[1]) for a in sys.argv if a.startswith("--stride=")), 1)
 segs = tuple(int(c) for c in argv[0].split(","))
 cout, ks, prec = int(argv[1]), int(argv[2]), argv[3]
 H, W = (int(argv[4]), int(argv[5])) if len(argv) > 5 else (1088, 1920)
@@ -20,13 +21,14 @@ r16c = lambda c: (c + 15) // 16 * 16
 xs = []
 for i, c in enumerate(segs):
     x = e.buf(f"x{i}", 1, H, W, c, cs=r16c(c)); x.base.normal_(); xs.append(x)
-r = e.buf("r", 1, H, W, cout, cs=r16c(cout)); r.base.normal_()
-o = e.buf("o", 1, H, W, cout, cs=r16c(cout))
+Ho, Wo = (H + 2 * (ks // 2) - ks) // stride + 1, (W + 2 * (ks // 2) - ks) // stride + 1
+r = e.buf("r", 1, Ho, Wo, cout, cs=r16c(cout)); r.base.normal_()
+o = e.buf("o", 1, Ho, Wo, cout, cs=r16c(cout))
 w = torch.nn.Parameter((torch.randn(cout, cin, ks, ks) * 0.05).cuda()); b = torch.nn.Parameter(torch.zeros(cout).cuda())
 pk = e.pack(("p",), w, b, segs, False)
-variants = {"f32-act+res": lambda: e._conv_f32(pk, xs, o, 1, None, 0.01, r, None, None),
-            "f32-act": lambda: e._conv_f32(pk, xs, o, 1, None, 0.01, None, None, None)}
-if e.s16_capable(pk):
+variants = {"f32-act+res": lambda: e._conv_f32(pk, xs, o, stride, None, 0.01, r, None, None),
+            "f32-act": lambda: e._conv_f32(pk, xs, o, stride, None, 0.01, None, None, None)}
+if e.s16_capable(pk, stride):
     only = []
     for x in xs:
         v = e.s16_pack(x)
@@ -70,8 +72,8 @@ for rnd in range(5):
         for _ in range(10): fn()
         ev1.record(); torch.cuda.synchronize()
         times[k].append(ev0.elapsed_time(ev1) / 10)
-fl = 2.0 * H * W * cin * cout * ks * ks
-print(f"{segs}->{cout} k{ks} {prec} {H}x{W}")
+fl = 2.0 * Ho * Wo * cin * cout * ks * ks
+print(f"{segs}->{cout} k{ks} s{stride} {prec} {H}x{W}")
 for k, t in times.items():
     t = sorted(t); med = t[len(t) // 2]
     print(f"  {k:28s}: median {med:.3f} ms (min {t[0]:.3f})  {fl/med/1e9:6.1f} TFLOP/s  frac of 833: {fl/med/1e9/833.3:.3f}")
