@@ -29,6 +29,10 @@ def test_reference_style_checkpoints_load(tmp_path):
     im = IntraNoAR()
     im.load_state_dict(S.get_state_dict(p2), strict=True)
     assert torch.equal(im.state_dict()["enc.0.conv1.weight"], si["enc.0.conv1.weight"])
+    # step-size accessors (video_model.py:255-261, image_model.py:50-52)
+    q = m.get_curr_y_q(m.y_q_scale[1:3])
+    assert q.shape == (2, 96, 1, 1) and torch.equal(q, torch.clamp_min(sd["y_q_basic"], 0.5) * sd["y_q_scale"][1:3])
+    assert m.get_curr_mv_y_q(0.7).shape == (1, 64, 1, 1) and im.get_curr_q(1.0).shape == (1, 192, 1, 1)
     # the wrapper prefixes the codec's keys with "dmc." (checkpoint.py:37-42, save_dcvc_weights.py:12-15)
     from vcm_ts_amd.dcvc_hem import build_model, make_cfg
 

@@ -474,6 +474,15 @@ class DMC(CodecBase):
         ckpt = S.get_state_dict(ckpt_path)
         return ckpt["y_q_scale"].reshape(-1), ckpt["mv_y_q_scale"].reshape(-1)
 
+    def get_curr_mv_y_q(self, q_scale):
+        """video_model.py:255-257: max(mv_y_q_basic, 0.5) * q_scale (the kernels apply the same product per channel,
+        Engine.scale_channels; this accessor is for callers that inspect the step sizes)."""
+        return torch.clamp_min(self.P("mv_y_q_basic"), 0.5) * q_scale
+
+    def get_curr_y_q(self, q_scale):
+        """video_model.py:259-261."""
+        return torch.clamp_min(self.P("y_q_basic"), 0.5) * q_scale
+
     # ------------------------------------------------------------------ shared analysis
     def _mv_side(self, net: Net, dpb_v, mv_y: View, mv_z_hat: View, N, q_mv, k, mode, decode=False):
         """mv hyper-decoder -> prior fusion -> dual prior -> mv_y_hat (in DPB set k)."""

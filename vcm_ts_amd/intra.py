@@ -41,6 +41,10 @@ class IntraNoAR(CodecBase):
         net.conv("refine.1", u, out=x_hat, out_slope="clamp01" if clamp else None)
         return x_hat
 
+    def get_curr_q(self, q_scale):
+        """image_model.py:50-52: max(q_basic, 0.5) * q_scale."""
+        return torch.clamp_min(self.P("q_basic"), 0.5) * q_scale
+
     def _run(self, x, q_scale, mode):
         e = self.engine()
         net = self._net
