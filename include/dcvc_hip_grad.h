@@ -51,6 +51,21 @@ int dcvc_conv_pack_weights_dev(const float *w, const float *b, int32_t Cout, int
                                int32_t nseg, const int32_t *seg_C, int32_t cin_offset, int32_t pixel_shuffle,
                                int32_t precision, int32_t transposed, float *wpack, float *bpack, void *stream);
 
+/* The same jobs for every layer of a model in ONE launch (a training step re-packs ~370 filters after each optimiser
+ * step).  A job is the argument list of dcvc_conv_pack_weights_dev; the plan keeps the jobs on the device.
+ * create: synchronous (allocates, copies the table); run: one stream-ordered launch; the pointers in the jobs must stay
+ * valid for the plan's life.  Results are identical to the per-layer calls. */
+typedef struct {
+    const float *w, *b;
+    int32_t Cout, Cin_total, ks, nseg;
+    int32_t seg_C[DCVC_MAX_SEG];
+    int32_t cin_offset, pixel_shuffle, precision, transposed;
+    float *wpack, *bpack;
+} dcvc_pack_job;
+int dcvc_pack_plan_create(const dcvc_pack_job *jobs, int32_t n, void **plan);
+int dcvc_pack_plan_run(void *plan, void *stream);
+void dcvc_pack_plan_destroy(void *plan);
+
 typedef struct {
     const float *dout;    /* gradient of the layer's output view (N, Ho*m, Wo*m, .), m = 2 if pixel_shuffle */
     int32_t dout_cs;

@@ -219,3 +219,46 @@ def test_training_step_is_bit_reproducible():
         for k in ga:
             assert torch.equal(ga[k], gb[k]), k
     m._noise_override = None
+
+
+def test_batch_pack_plan_equals_per_layer_packing():
+    """Engine.repack_all (dcvc_pack_plan_*: every device-packed filter of the model in one launch after an optimiser
+    step) leaves exactly the bytes the per-layer dcvc_conv_pack_weights_dev calls write -- forward packings (incl.
+    PixelShuffle order, channel slices, several segments) and the flipped / transposed data-gradient packings."""
+    import ctypes as C
+
+    from vcm_ts_amd import lib
+    from vcm_ts_amd.dcvc_hem import build_model, make_cfg
+
+    dev = torch.device("cuda:0")
+    model = build_model(make_cfg(), precision="fp16x3").to(dev).train()
+    model.activate_modules_all()
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-4)
+    clip = torch.rand(4, 4, 3, 64, 64, generator=torch.Generator().manual_seed(5)).to(dev)
+    dpb = {"ref_frame": clip[:, 0], "ref_feature": None, "ref_y": None, "ref_mv_y": None}
+    e = model.dmc.engine()
+    for t in (1, 2, 3):
+        opt.zero_grad()
+        r = model("single_multi", clip[:, t], clip[:, t], "mse", ["bpp"], perceptual_loss=False, dpb=dpb)
+        r["loss_to_opt"].backward()
+        opt.step()
+        dpb = r["dpb"]
+    assert e._plan is not None and e._plan[1] >= 300   # both kinds of picture have run: ~370 packings
+    n_before = len(e._dev_packs)
+    e.repack_all()                                     # the last optimiser step made every packing stale
+    assert e._plan[1] == n_before == len(e._dev_packs)
+    calls = 0
+    for pk in e._dev_packs:
+        w, b, Cout, CinT, ks, seg_C, off, ps, transposed = pk.job
+        assert pk.version == (w._version, None if pk.bias is None else pk.bias._version, w.data_ptr())
+        w_ref, b_ref = torch.full_like(pk.w, float("nan")), torch.full_like(pk.b, float("nan"))
+        segs = (C.c_int32 * len(seg_C))(*seg_C)
+        lib.check(e.L.dcvc_conv_pack_weights_dev(w.data_ptr(), None if b is None else b.data_ptr(), Cout, CinT, ks, len(seg_C),
+                                                 segs, off, ps, pk.precision, transposed, w_ref.data_ptr(), b_ref.data_ptr(),
+                                                 e.stream()), "pack")
+        assert torch.equal(pk.w.view(torch.int32), w_ref.view(torch.int32)), pk.key
+        assert torch.equal(pk.b.view(torch.int32), b_ref.view(torch.int32)), pk.key
+        calls += 1
+    assert calls == n_before
+    e.repack_all()  # nothing changed since: no launch, plan kept
+    assert e._plan[1] == n_before

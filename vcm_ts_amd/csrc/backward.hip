@@ -15,6 +15,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string.h>
+#include <vector>
 
 #include "dcvc_hip_grad.h"
 
@@ -61,8 +62,7 @@ struct PackK {
     int64_t total;  // packed elements (chunks * T * 4 * cp * 4)
 };
 
-__global__ void pack_kernel(const PackK a) {
-    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void pack_body(const PackK &a, const int64_t gid) {
     if (gid < a.cp) {
         float bv = 0.f;
         if (!a.transposed && a.b && gid < a.Npk) {
@@ -103,6 +103,18 @@ __global__ void pack_kernel(const PackK a) {
         base[((((size_t)cg * a.T + t) * 4 + h) * a.cp + np) * 8 + jj] = hi;
         base[((((size_t)cg * a.T + t) * 4 + 2 + h) * a.cp + np) * 8 + jj] = lo;
     }
+}
+
+__global__ void pack_kernel(const PackK a) { pack_body(a, (int64_t)blockIdx.x * blockDim.x + threadIdx.x); }
+
+// every layer of a plan in one launch: block b belongs to the entry e with first[e] <= b < first[e + 1]
+__global__ void pack_batch_kernel(const PackK *__restrict__ table, const int *__restrict__ first, int n) {
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (first[mid] <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    pack_body(table[lo], (int64_t)(blockIdx.x - first[lo]) * blockDim.x + threadIdx.x);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -835,15 +847,13 @@ __global__ void sq_err_bwd_kernel(const float *__restrict__ a, int a_cs, const f
 }  // namespace
 
 // =============================================================================================
-extern "C" int dcvc_conv_pack_weights_dev(const float *w, const float *b, int32_t Cout, int32_t Cin_total, int32_t ks,
-                                          int32_t nseg, const int32_t *seg_C, int32_t cin_offset, int32_t pixel_shuffle,
-                                          int32_t precision, int32_t transposed, float *wpack, float *bpack,
-                                          void *stream) {
+static int make_pack(PackK &k, const float *w, const float *b, int32_t Cout, int32_t Cin_total, int32_t ks, int32_t nseg,
+                     const int32_t *seg_C, int32_t cin_offset, int32_t pixel_shuffle, int32_t precision,
+                     int32_t transposed, float *wpack, float *bpack) {
     if (!w || !wpack || !bpack || !seg_C || nseg < 1 || nseg > DCVC_MAX_SEG || (ks != 1 && ks != 3 && ks != 7))
         return DCVC_E_ARG;
     if (precision != DCVC_PREC_FP32 && precision != DCVC_PREC_FP16X3) return DCVC_E_ARG;
     if (transposed && (nseg != 1 || pixel_shuffle)) return DCVC_E_ARG;
-    PackK k;
     memset(&k, 0, sizeof(k));
     k.w = w;
     k.b = b;
@@ -879,8 +889,71 @@ extern "C" int dcvc_conv_pack_weights_dev(const float *w, const float *b, int32_
     if (pixel_shuffle && (k.Npk & 3)) return DCVC_E_ARG;
     k.cp = round_up(k.Npk, 32);
     k.total = (int64_t)chunks * k.T * 4 * k.cp * 4;
+    return DCVC_OK;
+}
+
+extern "C" int dcvc_conv_pack_weights_dev(const float *w, const float *b, int32_t Cout, int32_t Cin_total, int32_t ks,
+                                          int32_t nseg, const int32_t *seg_C, int32_t cin_offset, int32_t pixel_shuffle,
+                                          int32_t precision, int32_t transposed, float *wpack, float *bpack,
+                                          void *stream) {
+    PackK k;
+    const int rc = make_pack(k, w, b, Cout, Cin_total, ks, nseg, seg_C, cin_offset, pixel_shuffle, precision, transposed,
+                             wpack, bpack);
+    if (rc != DCVC_OK) return rc;
     hipLaunchKernelGGL(pack_kernel, dim3(nblk(k.total, 256)), dim3(256), 0, (hipStream_t)stream, k);
     RET_LAUNCH();
+}
+
+// A plan = the packing jobs of every layer of a model, resident on the device: one launch re-packs them all after an
+// optimiser step (a training step otherwise spends ~370 launches of a few microseconds each on this).
+struct PackPlan {
+    PackK *table;
+    int *first;
+    int n;
+    unsigned blocks;
+};
+
+extern "C" int dcvc_pack_plan_create(const dcvc_pack_job *jobs, int32_t n, void **plan) {
+    if (!jobs || n < 1 || !plan) return DCVC_E_ARG;
+    std::vector<PackK> table((size_t)n);
+    std::vector<int> first((size_t)n);
+    int64_t blocks = 0;
+    for (int i = 0; i < n; ++i) {
+        const dcvc_pack_job &j = jobs[i];
+        const int rc = make_pack(table[i], j.w, j.b, j.Cout, j.Cin_total, j.ks, j.nseg, j.seg_C, j.cin_offset,
+                                 j.pixel_shuffle, j.precision, j.transposed, j.wpack, j.bpack);
+        if (rc != DCVC_OK) return rc;
+        first[i] = (int)blocks;
+        blocks += nblk(table[i].total > table[i].cp ? table[i].total : table[i].cp, 256);
+        if (blocks > 0x7fffffff) return DCVC_E_ARG;
+    }
+    PackPlan *p = new PackPlan{nullptr, nullptr, n, (unsigned)blocks};
+    if (hipMalloc((void **)&p->table, sizeof(PackK) * (size_t)n) != hipSuccess ||
+        hipMalloc((void **)&p->first, sizeof(int) * (size_t)n) != hipSuccess ||
+        hipMemcpy(p->table, table.data(), sizeof(PackK) * (size_t)n, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(p->first, first.data(), sizeof(int) * (size_t)n, hipMemcpyHostToDevice) != hipSuccess) {
+        if (p->table) (void)hipFree(p->table);
+        if (p->first) (void)hipFree(p->first);
+        delete p;
+        return DCVC_E_LAUNCH;
+    }
+    *plan = p;
+    return DCVC_OK;
+}
+
+extern "C" int dcvc_pack_plan_run(void *plan, void *stream) {
+    PackPlan *p = (PackPlan *)plan;
+    if (!p || !p->table) return DCVC_E_ARG;
+    hipLaunchKernelGGL(pack_batch_kernel, dim3(p->blocks), dim3(256), 0, (hipStream_t)stream, p->table, p->first, p->n);
+    RET_LAUNCH();
+}
+
+extern "C" void dcvc_pack_plan_destroy(void *plan) {
+    PackPlan *p = (PackPlan *)plan;
+    if (!p) return;
+    (void)hipFree(p->table);
+    (void)hipFree(p->first);
+    delete p;
 }
 
 extern "C" int dcvc_conv_bwd_prologue(const dcvc_conv_bwd_args *a, void *stream) {

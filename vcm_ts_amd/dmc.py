@@ -202,7 +202,10 @@ class CodecBase(nn.Module):
         ver = tuple(self.P(f"{name}.f{i}.h")._version for i in (1, 2, 3, 4))
         c = self.engine().packs.get(key)
         if c is None or c[0] != ver:
-            blk = E.factorized_param_block(E.factorized_params(self._pmap, name)).to(self.device)
+            # assembled where the parameters live: while training this runs every step, and a host round trip per
+            # parameter (22 synchronising copies per picture) would stall the launch queue
+            rows = [self.P(f"{name}.f{i}.{k}") for i in (1, 2, 3) for k in "hba"] + [self.P(f"{name}.f4.h"), self.P(f"{name}.f4.b")]
+            blk = torch.stack([r.detach().float().reshape(-1) for r in rows]).contiguous().to(self.device)
             c = (ver, blk)
             self.engine().packs[key] = c
         return c[1]
@@ -600,6 +603,7 @@ class DMC(CodecBase):
         e = self.engine()
         e.tape = tape
         try:
+            e.repack_all()  # one launch instead of one per layer for every filter the last optimiser step changed
             N = x.shape[0]
             tape.qstate("mv", self.P("mv_y_q_basic"), self._qvec(mv_y_q_scale, N, "mv_y_q_scale"), N, 64)
             tape.qstate("y", self.P("y_q_basic"), self._qvec(y_q_scale, N, "y_q_scale"), N, 96)

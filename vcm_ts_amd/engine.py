@@ -16,6 +16,8 @@ import torch
 
 from . import lib
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None) or (lambda idx: torch.cuda.current_stream(idx).cuda_stream)
+
 
 def _r4(c):
     return (c + 3) // 4 * 4
@@ -92,7 +94,7 @@ class View:
 
 class PackedConv:
     __slots__ = ("w", "b", "ks", "Cout", "Cout_pad", "seg_C", "ps", "version", "precision", "weight", "bias",
-                 "cin_slice", "key", "s16", "small", "host")
+                 "cin_slice", "key", "s16", "small", "host", "job")
 
 
 class Engine:
@@ -105,9 +107,12 @@ class Engine:
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise RuntimeError("the HIP engine needs a GPU device (no CPU fallback exists)")
+        self._dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
         self.L = lib.hip()
         self.bufs = {}
         self.packs = {}
+        self._dev_packs = []   # device-packed layers in creation order (pack_dev): the jobs of repack_all()'s plan
+        self._plan = None      # (handle, number of jobs, weight pointers) of dcvc_pack_plan_*
         self.calls = 0
         self.profile = None  # set to {} to time every conv launch with HIP events (bench.py)
         self.profile_detail = None
@@ -123,7 +128,9 @@ class Engine:
 
     # ------------------------------------------------------------------ memory
     def stream(self):
-        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        # the raw handle of torch's current stream on this device (torch.cuda.current_stream() builds a Stream object
+        # per call: ~5 us, a few milliseconds per training step at ~800 launches)
+        return C.c_void_p(_raw_stream(self._dev_index))
 
     def _store(self, scratch=False):
         """Inference recycles one named workspace; a recorded (training) forward owns fresh buffers
@@ -287,6 +294,7 @@ class Engine:
             pk.precision = lib.PRECISIONS[self.precision]
             pk.key = key
             self.packs[key] = pk
+            self._dev_packs.append(pk)
         assert weight.is_contiguous() and weight.dtype == torch.float32 and weight.device == self.device
         segs = (C.c_int32 * len(seg_C))(*seg_C)
         lib.check(self.L.dcvc_conv_pack_weights_dev(weight.data_ptr(), None if (bias is None or transposed) else bias.data_ptr(),
@@ -295,7 +303,48 @@ class Engine:
                   f"conv_pack_weights_dev({key})")
         pk.version = ver
         pk.weight, pk.bias, pk.cin_slice = weight, bias, cin_slice
+        pk.job = (weight, None if (bias is None or transposed) else bias, Cout, CinT, ks, tuple(seg_C), off, int(ps),
+                  int(transposed))
         return pk
+
+    def repack_all(self):
+        """Training: bring every device-packed filter (forward and data-gradient packings) up to date with ONE launch.
+        The optimiser changes every weight every step, and ~370 per-layer packing launches cost more host time than
+        anything else in a batch-4 256x256 step; the plan (dcvc_pack_plan_*) holds all their jobs on the device.
+        Called at the start of a recorded forward; layers first seen later in the step pack themselves as before
+        (pack_dev) and join the plan at the next call."""
+        packs = self._dev_packs
+        if len(packs) < 8:
+            return
+        vers, stale = [], False
+        for pk in packs:
+            w, b = pk.job[0], pk.job[1]
+            ver = (w._version, None if pk.bias is None else pk.bias._version, w.data_ptr())
+            stale = stale or pk.version != ver
+            vers.append(ver)
+        if not stale:
+            return
+        ptrs = tuple(v[2] for v in vers)
+        if self._plan is None or self._plan[1] != len(packs) or self._plan[2] != ptrs:
+            if self._plan is not None:
+                self.L.dcvc_pack_plan_destroy(self._plan[0])
+                self._plan = None
+            jobs = (lib.PackJob * len(packs))()
+            for j, pk in zip(jobs, packs):
+                w, b, Cout, CinT, ks, seg_C, off, ps, transposed = pk.job
+                j.w, j.b = w.data_ptr(), None if b is None else b.data_ptr()
+                j.Cout, j.Cin_total, j.ks, j.nseg = Cout, CinT, ks, len(seg_C)
+                for i, c in enumerate(seg_C):
+                    j.seg_C[i] = c
+                j.cin_offset, j.pixel_shuffle, j.precision, j.transposed = off, ps, pk.precision, transposed
+                j.wpack, j.bpack = pk.w.data_ptr(), pk.b.data_ptr()
+            handle = C.c_void_p()
+            torch.cuda.synchronize(self.device)  # create copies the table with a blocking call
+            lib.check(self.L.dcvc_pack_plan_create(jobs, len(packs), C.byref(handle)), "pack_plan_create")
+            self._plan = (handle, len(packs), ptrs)
+        lib.check(self.L.dcvc_pack_plan_run(self._plan[0], self.stream()), "pack_plan_run")
+        for pk, ver in zip(packs, vers):
+            pk.version = ver
 
     def pack(self, key, weight: torch.Tensor, bias, seg_C, ps, cin_slice=None) -> PackedConv:
         if self.tape is not None:

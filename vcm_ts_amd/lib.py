@@ -119,6 +119,14 @@ class WgradArgs(C.Structure):
     ]
 
 
+class PackJob(C.Structure):  # dcvc_pack_job (include/dcvc_hip_grad.h)
+    _fields_ = [
+        ("w", C.c_void_p), ("b", C.c_void_p), ("Cout", C.c_int32), ("Cin_total", C.c_int32), ("ks", C.c_int32),
+        ("nseg", C.c_int32), ("seg_C", C.c_int32 * 3), ("cin_offset", C.c_int32), ("pixel_shuffle", C.c_int32),
+        ("precision", C.c_int32), ("transposed", C.c_int32), ("wpack", C.c_void_p), ("bpack", C.c_void_p),
+    ]
+
+
 class DualPriorBwdArgs(C.Structure):
     _fields_ = [
         ("y", C.c_void_p), ("y_cs", C.c_int32), ("fusion", C.c_void_p), ("fusion_cs", C.c_int32),
@@ -169,6 +177,9 @@ _SIGS = {
     "dcvc_sq_err": [vp, i32, vp, i32, vp, vp, i32, i32, i32, vp],
     # include/dcvc_hip_grad.h
     "dcvc_conv_pack_weights_dev": [vp, vp, i32, i32, i32, i32, vp, i32, i32, i32, i32, vp, vp, vp],
+    "dcvc_pack_plan_create": [C.POINTER(PackJob), i32, C.POINTER(C.c_void_p)],
+    "dcvc_pack_plan_run": [vp, vp],
+    "dcvc_pack_plan_destroy": [vp],
     "dcvc_conv_bwd_prologue": [C.POINTER(ConvBwdArgs), vp],
     "dcvc_conv_wgrad": [C.POINTER(WgradArgs), vp],
     "dcvc_channel_dot": [vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, i32, vp],
@@ -210,6 +221,7 @@ def hip():
             fn = getattr(L, name)
             fn.argtypes = sig
             fn.restype = C.c_int
+        L.dcvc_pack_plan_destroy.restype = None
         L.dcvc_conv_pack_size.argtypes = [i32, i32, i32, vp, C.POINTER(i32)]
         L.dcvc_conv_pack_size.restype = i64
         L.dcvc_cdf_table_cols.argtypes = []
