@@ -58,6 +58,35 @@ def test_conv_backward(eng, case):
                        kw.pop("W"), seed=CONV_CASES.index(case), **kw) < 2e-5
 
 
+@pytest.fixture(scope="module")
+def eng_fast():
+    from vcm_ts_amd.engine import Engine
+
+    return Engine(torch.device("cuda:0"), "fp16x3")
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=[c["name"] for c in CONV_CASES])
+def test_conv_backward_fast_mode(eng_fast, case):
+    """The same layers in fast mode: forward and data gradient on the split-fp16 kernel (~3e-6), weight gradients of
+    stride-1 layers on the split-bf16 kernel (hi + lo operands, three MFMAs per product: ~2^-16 per product, 1e-5 of the
+    gradient's norm here), against torch.autograd in fp32 on the CPU."""
+    import grad_check as G
+
+    kw = dict(case)
+    name = kw.pop("name")
+    assert eng_fast.wgrad_split
+    if kw["ks"] == 7:  # 7x7 layers use the bf16 kernel only on request (include/dcvc_hip_grad.h): check that kernel too
+        os.environ["DCVC_WGRAD_SPLIT_7X7"] = "1"
+        try:
+            k7 = dict(kw)
+            assert G.conv_case(eng_fast, "f7_" + name, k7.pop("seg_C"), k7.pop("Cout"), k7.pop("ks"), k7.pop("stride"), k7.pop("H"),
+                               k7.pop("W"), seed=CONV_CASES.index(case), **k7) < 5e-5
+        finally:
+            del os.environ["DCVC_WGRAD_SPLIT_7X7"]
+    assert G.conv_case(eng_fast, "f_" + name, kw.pop("seg_C"), kw.pop("Cout"), kw.pop("ks"), kw.pop("stride"), kw.pop("H"),
+                       kw.pop("W"), seed=CONV_CASES.index(case), **kw) < 5e-5
+
+
 def test_resampling_backward(eng):
     import grad_check as G
 
@@ -66,8 +95,8 @@ def test_resampling_backward(eng):
 
 @pytest.mark.parametrize("precision", ["fp32", "fp16x3"])
 def test_frame_gradients_match_oracle_autograd(precision):
-    """fp16x3: forward and data-gradient convolutions on the split-fp16 MFMA kernel (weight gradients
-    stay fp32 MFMA)."""
+    """fp16x3: forward and data-gradient convolutions on the split-fp16 MFMA kernel, weight gradients of stride-1 layers on
+    the split-bf16 kernel."""
     import grad_check as G
 
     assert G.frame_case(size=64, N=2, second=True, verbose=False, precision=precision) < 2e-3

@@ -14,6 +14,7 @@
 // float atomics, exactly where ATen does.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 #include <vector>
 
@@ -324,6 +325,213 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradK a) {
             float s = 0.f;
 #pragma unroll
             for (int k = 0; k < 8; ++k) s += xs[k * 32 + tid];
+            a.bscratch[((size_t)blockIdx.x * (gridDim.y / a.nci) + cot) * 32 + tid] = s;
+        }
+    }
+}
+
+// The same weight gradient on the bf16 matrix cores (fast mode, stride 1): every fp32 operand is carried as
+// hi = bf16(v), lo = bf16(v - hi) and dY.X ~= hi.hi + hi.lo + lo.hi on v_mfma_f32_32x32x16_bf16 with fp32 accumulation --
+// K = 16 pixels per instruction instead of 2, 3 x 32 cycles instead of 8 x 64 per 16 pixels.  bf16 keeps fp32's
+// exponent, so gradients of any magnitude need no scaling; the dropped lo.lo term and the truncation of lo bound the
+// error at ~2^-16 of sum |dY||X| per product (the fixtures' tolerance for gradients is 5e-3).  The MFMA wants 8
+// CONSECUTIVE K (= pixels) per lane, i.e. both operands pixel-major: the staging pass transposes while it converts
+// (4 pixels x 4 channels per thread -> one 8-byte LDS write per channel and plane).  A filter tap shifts the pixel run
+// of X by kx elements; the shifted fragments are cut out of two aligned 16-byte reads with v_alignbit.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+// (a, b) -> packed bf16 pair of the values and of their residuals
+__device__ __forceinline__ void split_pair_bf16(float a, float b, unsigned &hi, unsigned &lo) {
+    hi = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){a, b}, bf16x2));
+    const float ra = a - __builtin_bit_cast(float, hi << 16), rb = b - __builtin_bit_cast(float, hi & 0xffff0000u);
+    lo = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){ra, rb}, bf16x2));
+}
+
+template <int KS>
+__global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const WgradK a) {
+    constexpr int R = 4, TW = 32;
+    constexpr int KY = KS == 7 ? 1 : KS, TG = KY * KS, PAD = KS / 2;
+    constexpr int PH = R - 1 + KY, PW = TW + KS - 1;
+    constexpr int XROW = 20;                                // dwords per (channel, patch row): 40 pixels >= PW
+    constexpr int XCH = (PH * XROW + 63) / 64 * 64 + 4;     // channel stride = 4 (mod 64) dwords: 16-byte reads of
+    constexpr int DCH = R * TW / 2 + 4;                     //   consecutive channels fall in distinct banks
+    constexpr int NXG = PH * 10;                            // 4-pixel groups of the X patch
+    __shared__ __attribute__((aligned(16))) unsigned lds[2 * 32 * XCH + 2 * 32 * DCH];
+    unsigned *xh = lds, *xl = lds + 32 * XCH, *dh = lds + 2 * 32 * XCH, *dl = dh + 32 * DCH;
+    static_assert(sizeof(lds) >= 4096 * 4 && PW <= 40, "epilogue reuses the buffer for the cross-wave reduction");
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int col = lane & 31, hh = lane >> 5;
+    const int cot = blockIdx.y / a.nci, cit = blockIdx.y % a.nci;
+    const int co0 = cot * 32, ci0 = cit * 32;
+    const int grp = blockIdx.z;
+    const int ky0 = KS == 7 ? grp : 0;
+
+    f32x16 acc[TG];
+#pragma unroll
+    for (int t = 0; t < TG; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    const bool do_bias = a.bscratch != nullptr && cit == 0 && grp == 0;
+    float bs[4] = {0.f, 0.f, 0.f, 0.f};
+
+    // staging items: (4-pixel group g, channel quad q).  dY: 32 groups x 8 quads = one per thread; X: NXG x 8, two per thread
+    constexpr int NX = (NXG * 8 + 255) / 256;
+    f32x4 rd[4], rx[NX][4];
+    const bool vd = !(a.dpre_cs & 3) && !((uintptr_t)a.dpre & 15);
+    const bool vx = !(a.x_cs & 3) && !((uintptr_t)a.x & 15);
+    auto load4 = [](const float *src, bool vec, int c, int C) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (vec) {
+            v = *(const f32x4 *)src;
+        } else {
+            v[0] = src[0];
+            if (c + 1 < C) v[1] = src[1];
+            if (c + 2 < C) v[2] = src[2];
+            if (c + 3 < C) v[3] = src[3];
+        }
+        return v;
+    };
+    const int q = tid & 7;
+    auto load_tile = [&](int tile) {
+        const int tx = tile % a.ntx, ty = (tile / a.ntx) % a.nty, n = tile / (a.ntx * a.nty);
+        {
+            const int g = tid >> 3, r = g >> 3, x4 = g & 7;
+            const int oy = ty * R + r, c = co0 + q * 4;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int ox = tx * TW + x4 * 4 + i;
+                rd[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (oy < a.Ho && ox < a.Wo && c < a.Cout)
+                    rd[i] = load4(a.dpre + (((size_t)n * a.Hd + oy) * a.Wd + ox) * a.dpre_cs + c, vd, c, a.Cout);
+            }
+        }
+        const int gy0 = ty * R - PAD + ky0, gx0 = tx * TW - PAD;
+#pragma unroll
+        for (int u = 0; u < NX; ++u) {
+            const int g = (tid + u * 256) >> 3;
+            const int py = g / 10, x4 = g - py * 10;
+            const int gy = gy0 + py, c = ci0 + q * 4;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int px = x4 * 4 + i, gx = gx0 + px;
+                rx[u][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (g < NXG && px < PW && gy >= 0 && gy < a.Hin && gx >= 0 && gx < a.Win && c < a.C)
+                    rx[u][i] = load4(a.x + (((size_t)n * a.Hin + gy) * a.Win + gx) * a.x_cs + c, vx, c, a.C);
+            }
+        }
+    };
+    auto store_tile = [&]() {
+        {
+            const int g = tid >> 3;
+            const int c = co0 + q * 4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float v[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = c + e < a.Cout ? rd[i][e] : 0.f;
+                if (do_bias) bs[e] += (v[0] + v[1]) + (v[2] + v[3]);
+                unsigned h0, h1, l0, l1;
+                split_pair_bf16(v[0], v[1], h0, l0);
+                split_pair_bf16(v[2], v[3], h1, l1);
+                *(u32x2 *)&dh[(q * 4 + e) * DCH + g * 2] = (u32x2){h0, h1};
+                *(u32x2 *)&dl[(q * 4 + e) * DCH + g * 2] = (u32x2){l0, l1};
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < NX; ++u) {
+            const int g = (tid + u * 256) >> 3;
+            if (g < NXG) {
+                const int py = g / 10, x4 = g - py * 10;
+                const int c = ci0 + q * 4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float v[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        v[i] = c + e < a.C ? rx[u][i][e] : 0.f;
+                        if (a.in_act) v[i] = v[i] > 0.f ? v[i] : v[i] * a.in_slope;
+                    }
+                    unsigned h0, h1, l0, l1;
+                    split_pair_bf16(v[0], v[1], h0, l0);
+                    split_pair_bf16(v[2], v[3], h1, l1);
+                    *(u32x2 *)&xh[(q * 4 + e) * XCH + py * XROW + x4 * 2] = (u32x2){h0, h1};
+                    *(u32x2 *)&xl[(q * 4 + e) * XCH + py * XROW + x4 * 2] = (u32x2){l0, l1};
+                }
+            }
+        }
+    };
+
+    const int ntiles = a.N * a.nty * a.ntx;
+    if ((int)blockIdx.x < ntiles) load_tile(blockIdx.x);
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        __syncthreads();
+        store_tile();
+        __syncthreads();
+        if (tile + (int)gridDim.x < ntiles) load_tile(tile + gridDim.x);
+        const int r = wave;  // one output row of the tile per wave; K = its 32 pixels in two steps of 16
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int ao = col * DCH + r * 16 + ks * 8 + hh * 4;
+            const bf16x8 ah = __builtin_bit_cast(bf16x8, *(const u32x4 *)&dh[ao]);
+            const bf16x8 al = __builtin_bit_cast(bf16x8, *(const u32x4 *)&dl[ao]);
+#pragma unroll
+            for (int ky = 0; ky < KY; ++ky) {
+                const int bo = col * XCH + (r + ky) * XROW + ks * 8 + hh * 4;
+                unsigned wh[8], wl[8];
+                *(u32x4 *)&wh[0] = *(const u32x4 *)&xh[bo];
+                *(u32x4 *)&wl[0] = *(const u32x4 *)&xl[bo];
+                if (KS > 1) {
+                    *(u32x4 *)&wh[4] = *(const u32x4 *)&xh[bo + 4];
+                    *(u32x4 *)&wl[4] = *(const u32x4 *)&xl[bo + 4];
+                }
+#pragma unroll
+                for (int kx = 0; kx < KS; ++kx) {
+                    u32x4 fh, fl;
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) {
+                        const int w0 = d + kx / 2;
+                        if (kx & 1) {
+                            fh[d] = __builtin_amdgcn_alignbit(wh[w0 + 1], wh[w0], 16);
+                            fl[d] = __builtin_amdgcn_alignbit(wl[w0 + 1], wl[w0], 16);
+                        } else {
+                            fh[d] = wh[w0];
+                            fl[d] = wl[w0];
+                        }
+                    }
+                    const bf16x8 bh = __builtin_bit_cast(bf16x8, fh), bl = __builtin_bit_cast(bf16x8, fl);
+                    const int t = ky * KS + kx;
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[t], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // cross-wave reduction, one tap at a time, then the block's partial goes to scratch (layout of wgrad_kernel)
+    float *xs = (float *)lds;
+    const int nct = gridDim.y;
+#pragma unroll
+    for (int t = 0; t < TG; ++t) {
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) xs[wave * 1024 + ((r & 3) + 8 * (r >> 2) + 4 * hh) * 32 + col] = acc[t][r];
+        __syncthreads();
+        float *dst = a.scratch + (((size_t)blockIdx.x * nct + blockIdx.y) * a.T + (grp * TG + t)) * 1024;
+        for (int i = tid; i < 1024; i += 256) dst[i] = (xs[i] + xs[1024 + i]) + (xs[2048 + i] + xs[3072 + i]);
+    }
+    if (do_bias) {  // thread (group g, quad q) holds the sums of channels 4q..4q+3 over its pixels
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 4; ++e) xs[(tid >> 3) * 32 + q * 4 + e] = bs[e];
+        __syncthreads();
+        if (tid < 32) {
+            float s = 0.f;
+#pragma unroll 8
+            for (int k = 0; k < 32; ++k) s += xs[k * 32 + tid];
             a.bscratch[((size_t)blockIdx.x * (gridDim.y / a.nci) + cot) * 32 + tid] = s;
         }
     }
@@ -976,6 +1184,7 @@ extern "C" int dcvc_conv_wgrad(const dcvc_conv_wgrad_args *a, void *stream) {
     if (!a || !a->x || !a->dpre || !a->dw || !a->scratch || a->N <= 0 || a->C <= 0 || a->Cout <= 0) return DCVC_E_ARG;
     if ((a->ks != 1 && a->ks != 3 && a->ks != 7) || (a->stride != 1 && a->stride != 2) || (a->ks == 7 && a->stride != 1))
         return DCVC_E_ARG;
+    if (a->precision != DCVC_PREC_FP32 && a->precision != DCVC_PREC_FP16X3) return DCVC_E_ARG;
     if (a->zs < 1 || (a->Ho - 1) * a->zs >= a->Hd || (a->Wo - 1) * a->zs >= a->Wd) return DCVC_E_ARG;
     if (a->cin_offset < 0 || a->cin_offset + a->C > a->Cin_total) return DCVC_E_ARG;
     const int pad = a->ks / 2;
@@ -1021,7 +1230,16 @@ extern "C" int dcvc_conv_wgrad(const dcvc_conv_wgrad_args *a, void *stream) {
     if (a->db) k.bscratch = a->scratch + (size_t)splits * nct * k.T * 1024;
     hipStream_t st = (hipStream_t)stream;
     dim3 grid((unsigned)splits, (unsigned)nct, (unsigned)groups);
-    if (a->ks == 3 && a->stride == 1) hipLaunchKernelGGL((wgrad_kernel<3, 1>), grid, dim3(256), 0, st, k);
+    // fast mode: bf16 hi/lo operands for the 3x3 and 1x1 stride-1 layers.  The 7x7 layers (SpyNet) stay on the fp32
+    // kernel: wgrad_bf16_kernel<7> is correct and run-to-run identical by itself (tests/test_gpu_backward.py), but with
+    // it on the weight-gradient stream two runs of a whole training picture differed in a few dozen elements of the
+    // flow gradient (1e-4 relative) -- an interaction not tracked down; the reproducibility test guards this choice.
+    const bool split = a->precision == DCVC_PREC_FP16X3 && a->stride == 1 && a->ks != 7;
+    const bool split7 = a->precision == DCVC_PREC_FP16X3 && a->ks == 7 && getenv("DCVC_WGRAD_SPLIT_7X7") != nullptr;
+    if (split && a->ks == 3) hipLaunchKernelGGL((wgrad_bf16_kernel<3>), grid, dim3(256), 0, st, k);
+    else if (split7) hipLaunchKernelGGL((wgrad_bf16_kernel<7>), grid, dim3(256), 0, st, k);
+    else if (split) hipLaunchKernelGGL((wgrad_bf16_kernel<1>), grid, dim3(256), 0, st, k);
+    else if (a->ks == 3 && a->stride == 1) hipLaunchKernelGGL((wgrad_kernel<3, 1>), grid, dim3(256), 0, st, k);
     else if (a->ks == 3) hipLaunchKernelGGL((wgrad_kernel<3, 2>), grid, dim3(256), 0, st, k);
     else if (a->ks == 1 && a->stride == 1) hipLaunchKernelGGL((wgrad_kernel<1, 1>), grid, dim3(256), 0, st, k);
     else if (a->ks == 1) hipLaunchKernelGGL((wgrad_kernel<1, 2>), grid, dim3(256), 0, st, k);

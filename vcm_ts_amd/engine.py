@@ -125,6 +125,9 @@ class Engine:
         # flags outputs beyond that magnitude in the status word (check_status() raises).  Off by default: it
         # costs VALU work in the epilogue; bench.py and the tests turn it on for a checked pass.
         self.range_check = os.environ.get("DCVC_RANGE_CHECK", "0") == "1"
+        # fast mode: weight gradients of stride-1 layers on the bf16 matrix cores (hi + lo operands, three products);
+        # DCVC_WGRAD_SPLIT=0 keeps them on the fp32 MFMA
+        self.wgrad_split = os.environ.get("DCVC_WGRAD_SPLIT", "1") != "0"
 
     # ------------------------------------------------------------------ memory
     def stream(self):

@@ -115,7 +115,7 @@ class WgradArgs(C.Structure):
         ("N", C.c_int32), ("Hin", C.c_int32), ("Win", C.c_int32), ("Ho", C.c_int32), ("Wo", C.c_int32),
         ("Cout", C.c_int32), ("ks", C.c_int32), ("stride", C.c_int32), ("dw", C.c_void_p), ("Cin_total", C.c_int32),
         ("cin_offset", C.c_int32), ("scratch", C.c_void_p), ("scratch_floats", C.c_int64), ("overwrite", C.c_int32),
-        ("db", C.c_void_p),
+        ("db", C.c_void_p), ("precision", C.c_int32),
     ]
 
 
