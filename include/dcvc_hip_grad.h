@@ -9,6 +9,7 @@
  *   dcvc_conv_pack_weights_dev   device-side twin of dcvc_conv_pack_weights (weights change every
  *                                optimiser step); transposed=1 packs the flipped, channel-
  *                                transposed filter so that dcvc_conv2d computes the data gradient
+ *   dcvc_pack_plan_create/_run/_destroy   the same packing jobs for every layer of a model in one launch
  *   dcvc_conv_bwd_prologue       backward of the fused epilogue of dcvc_conv2d: activation mask,
  *                                (gated) residual fan-out, inverse PixelShuffle, zero insertion
  *                                for stride-2 layers                layers.py:18-127
