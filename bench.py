@@ -233,7 +233,7 @@ def train_workload(args, dev, rank, world):
     out = {"metric": "trainer step pictures/sec (batch 4 x 256x256 per GPU, bpp+MSE, AdamW)", "value": round(world * batch * args.steps / dt, 2),
            "unit": "pictures/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-           "dtype": "f32" if prec == "fp32" else "f32 (fp16x3 split-MFMA convolutions; weight gradients: split-bf16 MFMA for 3x3 / 1x1 stride-1 layers, fp32 MFMA otherwise)", "data": "synthetic",
+           "dtype": "f32" if prec == "fp32" else "f32 (fp16x3 split-MFMA convolutions; weight gradients: split-bf16 MFMA for stride-1 layers, fp32 MFMA for stride-2 layers)", "data": "synthetic",
            "config": {"workload": "trainer.py / trainer_multi.py optimiser step (configs[2] at N=1, configs[3] at N>1): "
                                   "forward_one_frame + backward + AdamW, single mode, uniform-random clips, random-init weights",
                       "batch_per_gpu": batch, "global_batch": batch * world, "height": size, "width": size, "precision": prec,

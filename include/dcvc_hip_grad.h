@@ -108,9 +108,8 @@ typedef struct {
     float *db;            /* optional (Cout): bias gradient = sum of dpre over samples and pixels, written (=)
                              from the same pass over dpre */
     int32_t precision;    /* DCVC_PREC_FP32: fp32 MFMA (exact fmaf chains).  DCVC_PREC_FP16X3 (the engine's fast mode),
-                             3x3 / 1x1 stride-1 layers: operands split into bf16 hi + lo, three bf16 MFMAs per product,
-                             fp32 accumulation -- relative error ~2^-16 of sum |dY||X|; stride-2 and 7x7 layers stay
-                             fp32 (DCVC_WGRAD_SPLIT_7X7=1 in the environment moves the 7x7 layers over as well) */
+                             stride-1 layers: operands split into bf16 hi + lo, three bf16 MFMAs per product, fp32
+                             accumulation -- relative error ~2^-16 of sum |dY||X|; stride-2 layers stay fp32 */
 } dcvc_conv_wgrad_args;
 
 int64_t dcvc_conv_wgrad_scratch_min(int32_t Cout, int32_t C, int32_t ks);

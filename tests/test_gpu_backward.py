@@ -68,21 +68,13 @@ def eng_fast():
 @pytest.mark.parametrize("case", CONV_CASES, ids=[c["name"] for c in CONV_CASES])
 def test_conv_backward_fast_mode(eng_fast, case):
     """The same layers in fast mode: forward and data gradient on the split-fp16 kernel (~3e-6), weight gradients of
-    stride-1 layers on the split-bf16 kernel (hi + lo operands, three MFMAs per product: ~2^-16 per product, 1e-5 of the
+    stride-1 layers (1x1, 3x3, 7x7) on the split-bf16 kernel (hi + lo operands, three MFMAs per product: ~2^-16 per product, 1e-5 of the
     gradient's norm here), against torch.autograd in fp32 on the CPU."""
     import grad_check as G
 
     kw = dict(case)
     name = kw.pop("name")
     assert eng_fast.wgrad_split
-    if kw["ks"] == 7:  # 7x7 layers use the bf16 kernel only on request (include/dcvc_hip_grad.h): check that kernel too
-        os.environ["DCVC_WGRAD_SPLIT_7X7"] = "1"
-        try:
-            k7 = dict(kw)
-            assert G.conv_case(eng_fast, "f7_" + name, k7.pop("seg_C"), k7.pop("Cout"), k7.pop("ks"), k7.pop("stride"), k7.pop("H"),
-                               k7.pop("W"), seed=CONV_CASES.index(case), **k7) < 5e-5
-        finally:
-            del os.environ["DCVC_WGRAD_SPLIT_7X7"]
     assert G.conv_case(eng_fast, "f_" + name, kw.pop("seg_C"), kw.pop("Cout"), kw.pop("ks"), kw.pop("stride"), kw.pop("H"),
                        kw.pop("W"), seed=CONV_CASES.index(case), **kw) < 5e-5
 
@@ -208,10 +200,13 @@ def test_frozen_parameters_get_no_gradient_and_dpb_inputs_get_one():
         assert v.grad is not None and torch.isfinite(v.grad).all() and float(v.grad.abs().sum()) > 0, k
 
 
-def test_training_step_is_bit_reproducible():
-    """Two runs of the same training-mode picture (first-after-I and with a full DPB, batch 2) give
-    bit-identical losses and gradients: grid_sample's source scatter is summed in 64-bit fixed point, the
-    bilinear upsampling adjoint is a gather, every other reduction has a fixed order (no float atomics left)."""
+@pytest.mark.parametrize("N,size", [(2, 128), (4, 256), (3, 192), (1, 384)])
+def test_training_step_is_bit_reproducible(N, size):
+    """Three runs of the same training-mode pictures (first-after-I and with a full DPB) give bit-identical losses and
+    gradients: grid_sample's source scatter is summed in 64-bit fixed point, the bilinear upsampling adjoint is a
+    gather, every other reduction has a fixed order (no float atomics left).  Several sizes, incl. configs[2]'s batch
+    4 x 256x256: round 2 found the flow gradient of warp_bwd differing run to run at every size but the first while
+    the weight-gradient stream was busy (backward.hip, warp_bwd_kernel)."""
     from vcm_ts_amd.dmc import DMC
     from vcm_ts_amd.synthetic import frames
 
@@ -219,7 +214,6 @@ def test_training_step_is_bit_reproducible():
     m = DMC(precision="fp16x3").to(dev).train()
     for p in m.parameters():
         p.requires_grad_(True)
-    N, size = 2, 128
     fr = frames(9, N * 3, size, size)
     x0, x1, x2 = (torch.from_numpy(fr[k * N:(k + 1) * N]).to(dev) for k in range(3))
     g = torch.Generator().manual_seed(3)
@@ -241,12 +235,13 @@ def test_training_step_is_bit_reproducible():
             dpb = {k: v.detach() for k, v in out["dpb"].items()}
         return grads
 
-    a, b = run(), run()
-    for (la, ga), (lb, gb) in zip(a, b):
-        assert torch.equal(la, lb)
-        assert ga.keys() == gb.keys() and len(ga) > 300
-        for k in ga:
-            assert torch.equal(ga[k], gb[k]), k
+    a = run()
+    for b in (run(), run()):
+        for (la, ga), (lb, gb) in zip(a, b):
+            assert torch.equal(la, lb)
+            assert ga.keys() == gb.keys() and len(ga) > 300
+            for k in ga:
+                assert torch.equal(ga[k], gb[k]), k
     m._noise_override = None
 
 

@@ -1,6 +1,6 @@
 """Which parameter gradients differ between identical training-mode runs of two pictures (developer diagnostic;
 the assertion lives in tests/test_gpu_backward.py::test_training_step_is_bit_reproducible).
-DCVC_WGRAD_SPLIT_7X7=1 python3 tools/repro_check.py shows the run-to-run difference described in backward.hip."""
+usage: repro_check.py [N size]   (round 2 used it to bisect the run-to-run difference of warp_bwd_kernel, backward.hip)"""
 import os, sys
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -12,7 +12,7 @@ dev = torch.device("cuda:0")
 m = DMC(precision="fp16x3").to(dev).train()
 for p in m.parameters():
     p.requires_grad_(True)
-N, size = 2, 128
+N, size = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (2, 128)
 fr = frames(9, N * 3, size, size)
 x0, x1, x2 = (torch.from_numpy(fr[k * N:(k + 1) * N]).to(dev) for k in range(3))
 g = torch.Generator().manual_seed(3)

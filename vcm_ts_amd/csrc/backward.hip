@@ -679,8 +679,12 @@ __global__ void fix_finish_kernel(unsigned long long *__restrict__ fix, float *_
     if (v) dst[(gid / C) * dst_cs + gid % C] += (float)((double)v * (1.0 / 68719476736.0));
 }
 
-// One thread per (pixel, channel): scatter into dsrc with atomics, reduce the flow gradient
-// over the channels of a pixel through LDS (a block holds whole pixels: 256 % Cl == 0 or Cl == C loop).
+// One thread per (pixel, channel group): scatter into dsrc with integer atomics, reduce the flow gradient over the Cl
+// lanes of a pixel (consecutive lanes of one wave) with a shuffle butterfly.  Round 2: this reduction used to go through
+// LDS (write, barrier, lane 0 sums); with weight-gradient kernels running on the second stream its x component came out
+// different in a few pixels from run to run (tools/repro_check.py at batch 4 x 256x256: 134 parameter gradients), and
+// identical again with this version -- the mechanism was not identified (inputs and every other buffer were bitwise
+// equal), so the guard is tests/test_gpu_backward.py::test_training_step_is_bit_reproducible at several sizes.
 __global__ void warp_bwd_kernel(const float *__restrict__ src, int src_cs, const float *__restrict__ flow, int flow_cs,
                                 const float *__restrict__ dout, int dout_cs, float *__restrict__ dsrc, int dsrc_cs,
                                 float *__restrict__ dflow, int dflow_cs, int N, int H, int W, int C,
@@ -728,19 +732,14 @@ __global__ void warp_bwd_kernel(const float *__restrict__ src, int src_cs, const
         gy_acc *= my;
     }
     if (!dflow) return;
-    __shared__ float sx[256], sy[256];
-    const int t = threadIdx.y * blockDim.x + threadIdx.x;
-    sx[t] = gx_acc;
-    sy[t] = gy_acc;
-    __syncthreads();
+    // the Cl (<= 64, a power of two) lanes of a pixel are consecutive lanes of one wave: butterfly sum in a fixed order
+    for (int m = (int)blockDim.x >> 1; m >= 1; m >>= 1) {
+        gx_acc += __shfl_xor(gx_acc, m);
+        gy_acc += __shfl_xor(gy_acc, m);
+    }
     if (threadIdx.x == 0 && live) {
-        float ax = 0.f, ay = 0.f;
-        for (int k = 0; k < (int)blockDim.x; ++k) {
-            ax += sx[t + k];
-            ay += sy[t + k];
-        }
-        dflow[pix * dflow_cs] += ax;
-        dflow[pix * dflow_cs + 1] += ay;
+        dflow[pix * dflow_cs] += gx_acc;
+        dflow[pix * dflow_cs + 1] += gy_acc;
     }
 }
 
@@ -1230,14 +1229,9 @@ extern "C" int dcvc_conv_wgrad(const dcvc_conv_wgrad_args *a, void *stream) {
     if (a->db) k.bscratch = a->scratch + (size_t)splits * nct * k.T * 1024;
     hipStream_t st = (hipStream_t)stream;
     dim3 grid((unsigned)splits, (unsigned)nct, (unsigned)groups);
-    // fast mode: bf16 hi/lo operands for the 3x3 and 1x1 stride-1 layers.  The 7x7 layers (SpyNet) stay on the fp32
-    // kernel: wgrad_bf16_kernel<7> is correct and run-to-run identical by itself (tests/test_gpu_backward.py), but with
-    // it on the weight-gradient stream two runs of a whole training picture differed in a few dozen elements of the
-    // flow gradient (1e-4 relative) -- an interaction not tracked down; the reproducibility test guards this choice.
-    const bool split = a->precision == DCVC_PREC_FP16X3 && a->stride == 1 && a->ks != 7;
-    const bool split7 = a->precision == DCVC_PREC_FP16X3 && a->ks == 7 && getenv("DCVC_WGRAD_SPLIT_7X7") != nullptr;
+    const bool split = a->precision == DCVC_PREC_FP16X3 && a->stride == 1;  // fast mode: bf16 hi/lo operands
     if (split && a->ks == 3) hipLaunchKernelGGL((wgrad_bf16_kernel<3>), grid, dim3(256), 0, st, k);
-    else if (split7) hipLaunchKernelGGL((wgrad_bf16_kernel<7>), grid, dim3(256), 0, st, k);
+    else if (split && a->ks == 7) hipLaunchKernelGGL((wgrad_bf16_kernel<7>), grid, dim3(256), 0, st, k);
     else if (split) hipLaunchKernelGGL((wgrad_bf16_kernel<1>), grid, dim3(256), 0, st, k);
     else if (a->ks == 3 && a->stride == 1) hipLaunchKernelGGL((wgrad_kernel<3, 1>), grid, dim3(256), 0, st, k);
     else if (a->ks == 3) hipLaunchKernelGGL((wgrad_kernel<3, 2>), grid, dim3(256), 0, st, k);

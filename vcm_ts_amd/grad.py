@@ -206,6 +206,7 @@ class Tape:
                 w.scratch, w.scratch_floats = sc.data_ptr(), sc.numel()
                 w.overwrite = int(whole)
                 w.precision = lib.PRECISIONS[e.precision] if e.wgrad_split else lib.PRECISIONS["fp32"]
+                w.precision = lib.PRECISIONS[e.precision] if e.wgrad_split else lib.PRECISIONS["fp32"]
                 if db is not None and si == 0:  # the bias gradient rides on the first segment's pass over dY
                     w.db = db.data_ptr()
                 lib.check(L.dcvc_conv_wgrad(C.byref(w), wstream), "conv_wgrad")
