@@ -681,10 +681,13 @@ __global__ void fix_finish_kernel(unsigned long long *__restrict__ fix, float *_
 
 // One thread per (pixel, channel group): scatter into dsrc with integer atomics, reduce the flow gradient over the Cl
 // lanes of a pixel (consecutive lanes of one wave) with a shuffle butterfly.  Round 2: this reduction used to go through
-// LDS (write, barrier, lane 0 sums); with weight-gradient kernels running on the second stream its x component came out
-// different in a few pixels from run to run (tools/repro_check.py at batch 4 x 256x256: 134 parameter gradients), and
-// identical again with this version -- the mechanism was not identified (inputs and every other buffer were bitwise
-// equal), so the guard is tests/test_gpu_backward.py::test_training_step_is_bit_reproducible at several sizes.
+// LDS (write, barrier, lane 0 sums); with the bf16 weight-gradient kernels running on the second stream its x component
+// came out different in a few pixels from run to run (tools/repro_check.py at batch 4 x 256x256: 134 parameter
+// gradients).  Reproduced in isolation by tools/warp_bwd_lds_probe.py (profiles/r02_warp_bwd_lds_probe.txt): every LDS
+// formulation tried (arrays padded, swapped, volatile, extra register copies; with or without the scatter's atomics in
+// the loop) differs run to run in the x component of a few pixels while bf16-MFMA kernels run on another stream, and
+// never alone or beside fp32-MFMA kernels; this shuffle version never differs.  Cause below the source level not
+// identified; tests/test_gpu_backward.py::test_training_step_is_bit_reproducible guards it at four sizes.
 __global__ void warp_bwd_kernel(const float *__restrict__ src, int src_cs, const float *__restrict__ flow, int flow_cs,
                                 const float *__restrict__ dout, int dout_cs, float *__restrict__ dsrc, int dsrc_cs,
                                 float *__restrict__ dflow, int dflow_cs, int N, int H, int W, int C,
