@@ -58,12 +58,12 @@ def host_cores():
 
 
 def kernel_source_hash():
-    """sha256 (16 hex) over the convolution kernel sources: a committed PMC figure is only quoted for the
-    kernels it was measured on."""
+    """sha256 (16 hex) over the convolution kernel sources and the build flags: a committed PMC figure is only
+    quoted for the kernels it was measured on."""
     import hashlib
 
     h = hashlib.sha256()
-    for name in ("conv_mfma.hip", "conv_s16.hip"):
+    for name in ("conv_mfma.hip", "conv_s16.hip", "Makefile"):
         with open(os.path.join(ROOT, "vcm_ts_amd", "csrc", name), "rb") as f:
             h.update(f.read())
     return h.hexdigest()[:16]
