@@ -529,6 +529,38 @@ def test_concurrent_gop_streams_encode_identically():
         assert torch.equal(recs[k][-1], res[k][2]["ref_frame"]), k
 
 
+def test_concurrent_gop_streams_are_repeatable_at_a_larger_size():
+    """The same property in the mode and at a size where kernels of the two streams really share the CUs (fast mode,
+    512x768, GOP 4), three concurrent runs and one sequential: identical payloads every time.  (Round 2 found one
+    TRAINING kernel whose result depended on what ran beside it; this guards the codec path.)"""
+    from vcm_ts_amd.dmc import DMC
+    from vcm_ts_amd.intra import IntraNoAR
+    from vcm_ts_amd.pipeline import ConcurrentGopEncoder
+
+    dev = torch.device("cuda:0")
+    make = lambda: (IntraNoAR(precision="fp16x3").to(dev).eval(), DMC(precision="fp16x3").to(dev).eval())
+    seqs = []
+    for k in range(2):
+        fr = frames(80 + k, 4, 512, 768)
+        seqs.append([torch.from_numpy(fr[t : t + 1]).to(dev) for t in range(4)])
+    cenc = ConcurrentGopEncoder(make, gop_size=4, streams=2)
+    first = cenc.encode_gops(seqs, 1.0, 1.0, 1.0)
+    last_recon = [first[k][2]["ref_frame"].clone() for k in range(2)]   # DPB tensors are views of recycled buffers
+    for _ in range(2):
+        again = cenc.encode_gops(seqs, 1.0, 1.0, 1.0)
+        for k in range(2):
+            assert [c[2] for c in again[k][0]] == [c[2] for c in first[k][0]], k
+    for k in range(2):
+        coded, bits, dpb = cenc.encoders[0].encode_gop(seqs[k], 1.0, 1.0, 1.0)
+        assert [c[2] for c in coded] == [c[2] for c in first[k][0]] and bits == first[k][1], k
+    recs = cenc.decode_gops([r[0] for r in first], 512, 768)
+    for k in range(2):
+        assert torch.equal(recs[k][-1], last_recon[k]), k
+    for enc in cenc.encoders:
+        enc.i_net.engine().release()
+        enc.p_net.engine().release()
+
+
 def test_config_c1_gop8_256_through_encode_decode_files(nets, tmp_path):
     """BASELINE configs[0] / SURVEY 8d C1: one 8-picture 256x256 GOP through the reference's own calls --
     IntraNoAR.encode_decode, then seven DMC.encode_decode with .bin files, q-scales 1.0 -- as
