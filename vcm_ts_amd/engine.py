@@ -238,6 +238,14 @@ class Engine:
     def release(self):
         self.bufs.clear()
 
+    def __del__(self):  # the pack plan owns a small device table (dcvc_pack_plan_create)
+        plan, self._plan = getattr(self, "_plan", None), None
+        if plan is not None:
+            try:
+                self.L.dcvc_pack_plan_destroy(plan[0])
+            except Exception:
+                pass
+
     def bytes_reserved(self):
         return sum(t.numel() * t.element_size() for t in self.bufs.values())
 
