@@ -1,0 +1,68 @@
+"""Build guards that need no GPU.
+
+The product library must hold NO packed-FP32 VALU instruction (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32): round 2
+traced a run-to-run difference of one kernel to such code running beside another stream's 16-bit MFMA kernels
+(DESIGN.md 4b), and an encoder and a decoder must compute the same bits whatever runs beside them.  The build switches
+the target feature off (vcm_ts_amd/csrc/Makefile, NOPK); this test checks the RESULT -- the shipped ISA -- so that a
+toolchain that stops honouring the flag, or a build that drops it, fails here and not in a decoder.
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import check_isa  # noqa: E402
+
+CSRC = os.path.join(ROOT, "vcm_ts_amd", "csrc")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+needs_toolchain = pytest.mark.skipif(not (os.path.exists(check_isa.OBJDUMP) and os.path.exists(HIPCC)),
+                                     reason="ROCm LLVM tools not installed")
+
+
+@needs_toolchain
+def test_product_library_has_no_packed_fp32_instructions():
+    census = check_isa.packed_fp32_census(os.path.join(CSRC, "libdcvc_hip.so"))
+    # one gfx950 code object per translation unit of the Makefile's HIPSRC
+    hipsrc = [ln for ln in open(os.path.join(CSRC, "Makefile")) if ln.startswith("HIPSRC")][0].split(":=")[1].split()
+    assert len(census) == len(hipsrc), (sorted(census), hipsrc)
+    assert sum(c["mfma"] for c in census.values()) > 1000  # the disassembly really is the kernels
+    offenders = {obj: c["packed"] for obj, c in census.items() if c["packed"]}
+    assert not offenders, offenders
+
+
+@needs_toolchain
+def test_the_guard_sees_packed_fp32_when_it_is_there(tmp_path):
+    """The same source with and without the build's flag: the checker must tell them apart (it is not vacuous), and
+    the device pass must accept the flag silently (the Makefile fails the build on its 'not a recognized feature')."""
+    src = tmp_path / "pk.hip"
+    src.write_text("#include <hip/hip_runtime.h>\n"
+                   "__global__ void k(float2 *a, const float2 *b) { int i = threadIdx.x; float2 x = a[i], y = b[i];\n"
+                   "  x.x = x.x * y.x + 1.f; x.y = x.y * y.y + 1.f; a[i] = x; }\n")
+    nopk = [ln for ln in open(os.path.join(CSRC, "Makefile")) if ln.startswith("NOPK")][0].split("?=")[1].split()
+    counts = {}
+    for tag, extra in (("plain", []), ("nopk", nopk)):
+        fb = tmp_path / f"{tag}.hipfb"
+        dev = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-fPIC", "-cuid=t", "--offload-device-only", *extra,
+                              "-c", str(src), "-o", str(fb)], capture_output=True, text=True)
+        assert dev.returncode == 0, dev.stderr
+        assert "not a recognized feature" not in dev.stderr, dev.stderr
+        obj, so = tmp_path / f"{tag}.o", tmp_path / f"lib{tag}.so"
+        subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-fPIC", "-cuid=t", "--offload-host-only", "-Xclang",
+                        "-fcuda-include-gpubinary", "-Xclang", str(fb), "-c", str(src), "-o", str(obj)], check=True,
+                       capture_output=True)
+        subprocess.run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(so), str(obj)], check=True,
+                       capture_output=True)
+        census = check_isa.packed_fp32_census(str(so))
+        assert len(census) == 1
+        counts[tag] = sum(sum(c["packed"].values()) for c in census.values())
+    assert counts["plain"] > 0 and counts["nopk"] == 0, counts
+
+
+def test_makefile_does_not_filter_compiler_diagnostics():
+    mk = open(os.path.join(CSRC, "Makefile")).read()
+    assert "grep -v" not in mk
+    assert "check-isa" in mk.split("all:")[1].splitlines()[0]

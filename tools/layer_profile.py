@@ -23,7 +23,7 @@ else:
     i_net.compress(seq[0], 1.0)
 torch.cuda.synchronize()
 agg = collections.OrderedDict()
-for a, b, fl, sig in e.profile_detail:
+for a, b, fl, sig, _note in e.profile_detail:
     d = agg.setdefault(sig, [0, 0.0, 0.0]); d[0] += 1; d[1] += a.elapsed_time(b); d[2] += fl
 tot = sum(v[1] for v in agg.values())
 print(f"total conv time {tot:.2f} ms, {sum(v[0] for v in agg.values())} launches, {sum(v[2] for v in agg.values())/tot/1e9:.1f} TFLOP/s")

@@ -514,7 +514,7 @@ class Engine:
         self.calls += 1
         return out
 
-    def _launch_conv(self, launch, pk, s0, Ho, Wo, stride, res, res2, tag=""):
+    def _launch_conv(self, launch, pk, s0, Ho, Wo, stride, res, res2, tag="", note=""):
         if self.profile is None:
             launch()
             return
@@ -530,7 +530,7 @@ class Engine:
         self.profile.setdefault(f"conv{pk.ks}x{pk.ks}s{stride}{tag}", []).append((ev0, ev1, flops, abytes))
         if self.profile_detail is not None:
             self.profile_detail.append((ev0, ev1, flops, f"k{pk.ks}s{stride}{tag} {pk.seg_C}->{pk.Cout}{'ps' if pk.ps else ''} "
-                                                         f"{s0.H}x{s0.W}"))
+                                                         f"{s0.H}x{s0.W}", note))
 
     def chan_partial_buf(self, name, pk: PackedConv, out: View, stride=1):
         """(buffer, rows per image) for the fused channel sums of a convolution writing `out`."""
@@ -576,8 +576,14 @@ class Engine:
         if chan_partial is not None:
             a.chan_partial = chan_partial.data_ptr()
         fn, what = (self.L.dcvc_conv2d_small, "conv2d_small") if small else (self.L.dcvc_conv2d, "conv2d")
+        note = ""
+        if self.profile_detail is not None:  # per-launch listing of tools/in_pipeline_detail.py: layer name and epilogue flags
+            note = (f"{pk.key[0][1] if isinstance(pk.key[0], tuple) and len(pk.key[0]) > 1 else pk.key[0]}"
+                    f" in_act={in_slope} out_act={out_slope} in_cs={[s.cs for s in srcs]} out_cs={out.cs}"
+                    f" res={None if res is None else res.cs} gate={gate is not None} res2={None if res2 is None else res2.cs}"
+                    f" chan_sums={chan_partial is not None}")
         self._launch_conv(lambda: lib.check(fn(C.byref(a), self.stream()), what), pk, s0, Ho, Wo, stride, res, res2,
-                          "small" if small else "")
+                          "small" if small else "", note)
         self.calls += 1
         self._rec("conv", pk, tuple(srcs), out, stride, in_slope, out_slope, res, gate, res2)
         return out
