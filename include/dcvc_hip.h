@@ -135,6 +135,20 @@ int dcvc_conv_small_pack_weights(const float *w, const float *b, int32_t Cout, i
                                  const int32_t *seg_C, void *wpack, float *bpack);
 int dcvc_conv2d_small(const dcvc_conv_args *a, void *stream);
 
+/* ---- 32-channel-chunk form of DCVC_PREC_FP16X3 (round 3) ------------------------------------------------------
+ * The same operator as dcvc_conv2d(DCVC_PREC_FP16X3) for stride-1 1x1 / 3x3 layers whose input segments are all
+ * multiples of 32 channels, on v_mfma_f32_16x16x32_f16 (vcm_ts_amd/csrc/conv_k32.hip): one tap of a 32-channel chunk
+ * is one K step.  Measured on MI355X the 16x16x32 shape sustains 1.19x the FLOP/s of 32x32x16 in the bare
+ * fragment-read + MFMA loop (profiles/r03_mfma_loop_probe.txt).  Same dcvc_conv_args (precision must be
+ * DCVC_PREC_FP16X3, stride 1, 16-byte-aligned epilogue: (Cout or Cout/4 with pixel shuffle) % 4 == 0 and aligned
+ * out / res / res2); `status` is cheap here (two VALU per four outputs) and meant to be always passed.  Weights from
+ * dcvc_conv_k32_pack_weights (HOST; returns DCVC_E_RANGE with the buffers written, clamped, when a |weight| >= 1023.5).
+ * Deterministic, but not bit-identical to dcvc_conv2d: the instruction sums 32 products per step instead of 16. */
+int64_t dcvc_conv_k32_pack_bytes(int32_t Cout, int32_t ks, int32_t nseg, const int32_t *seg_C, int32_t *cout_pad);
+int dcvc_conv_k32_pack_weights(const float *w, const float *b, int32_t Cout, int32_t ks, int32_t nseg,
+                               const int32_t *seg_C, int32_t pixel_shuffle, void *wpack, float *bpack);
+int dcvc_conv2d_k32(const dcvc_conv_args *a, void *stream);
+
 /* ---- pre-split activations ("S16") --------------------------------------------------------
  * The fast form of DCVC_PREC_FP16X3 for 3x3 stride-1 layers whose inputs were produced by another
  * convolution (vcm_ts_amd/csrc/conv_s16.hip).  An S16 tensor of C channels (C % 16 == 0) is PLANAR in

@@ -148,6 +148,96 @@ def test_small_cout_conv_matches_fp64_and_the_32_column_kernel(eng_split, case):
     assert (outs[True] - outs[False]).abs().max().item() < 2e-6 * scale + 2e-7 * want.abs().max().item()
 
 
+K32_CASES = [
+    # cin segments, cout, H, W, N, ps, in_slope, out_slope, res, gate, res2, cs of the inputs (None: dense)
+    ((64,), 64, 40, 72, 1, False, None, 0.01, True, False, False, None),      # ResBlock conv2 shape, partial tiles both ways
+    ((64,), 64, 33, 95, 2, False, 0.01, None, True, False, True, 128),        # res + res2, activation on load, slices of wider buffers
+    ((32, 64), 64, 48, 64, 1, False, None, None, False, False, False, None),  # two segments (recon first_conv)
+    ((128,), 128, 34, 66, 1, False, 0.0, None, True, False, False, None),     # two output-channel blocks (context_refine)
+    ((128,), 256, 18, 34, 2, True, None, 0.01, False, False, False, None),    # PixelShuffle
+    ((64,), 32, 16, 32, 1, False, None, 0.01, False, False, False, None),     # 32-column variant (BN = 32)
+    ((32,), 32, 50, 50, 1, False, None, None, True, True, False, None),       # gated residual (SE block), one chunk
+    ((96,), 144, 17, 33, 1, False, None, "clamp01", False, False, False, None),  # Cout padded to 160, clamp
+    ((192, 192, 96), 384, 9, 20, 1, False, None, 0.2, False, False, False, None),  # three segments, 15 chunks
+    ((64, 64), 64, 8, 32, 1, False, None, None, False, False, False, None),   # exactly one tile
+]
+
+
+@pytest.mark.parametrize("case", K32_CASES, ids=[f"k{i}" for i in range(len(K32_CASES))])
+def test_k32_conv_matches_fp64_and_the_32x32_kernel(eng_split, case):
+    """dcvc_conv2d_k32 (v_mfma_f32_16x16x32_f16, 32-channel chunks, conv_k32.hip) against an fp64 reference within the
+    split-fp16 bound of test_split_fp16_conv_matches_fp64, and against conv_mfma (32x32x16) on the same layer: same
+    operand values, another grouping of the sum -- fp32 rounding apart.  Both kernels are deterministic."""
+    segs, cout, H, W, N, ps, in_slope, out_slope, use_res, use_gate, use_res2, in_cs = case
+    eng = eng_split
+    g = torch.Generator().manual_seed(K32_CASES.index(case) + 90)
+    cin = sum(segs)
+    mag = torch.tensor([1e-3, 1.0, 20.0])[torch.randint(0, 3, (N, cin, 1, 1), generator=g)]
+    x = torch.randn(N, cin, H, W, generator=g) * mag
+    w = torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(cin * 9)
+    b = torch.randn(cout, generator=g) * 0.1
+    xin = x.double() if in_slope is None else F.leaky_relu(x.double(), in_slope)
+    want = F.conv2d(xin, w.double(), b.double(), padding=1)
+    scale = F.conv2d(xin.abs(), w.double().abs(), None, padding=1).max().item()
+    if out_slope == "clamp01":
+        want = want.clamp(0, 1)
+    elif out_slope is not None:
+        want = F.leaky_relu(want, out_slope)
+    if ps:
+        want = F.pixel_shuffle(want, 2)
+    res = res2 = gate = None
+    if use_res:
+        r = torch.randn(want.shape, generator=g)
+        res = to_view(eng, "k32/res", r)
+        if use_gate:
+            gt = torch.rand(N, want.shape[1], generator=g)
+            gate = gt.cuda().contiguous()
+            r = r * gt[:, :, None, None]
+        want = want + r.double()
+    if use_res2:
+        r2 = torch.randn(want.shape, generator=g)
+        res2 = to_view(eng, "k32/res2", r2)
+        want = want + r2.double()
+    pk = eng.pack(("k32", case), torch.nn.Parameter(w.cuda()), torch.nn.Parameter(b.cuda()), segs, ps)
+    views, c0 = [], 0
+    for i, c in enumerate(segs):
+        v = to_view(eng, f"k32/in{i}", x[:, c0 : c0 + c], cs=in_cs)
+        views.append(v)
+        c0 += c
+    outs = {}
+    for k32 in (True, False):
+        eng.use_k32 = k32
+        out = eng.buf(f"k32/out{int(k32)}", N, want.shape[2], want.shape[3], want.shape[1])
+        out.base.fill_(float("nan"))
+        assert eng.k32_capable(pk, 1, out, res, res2, gate) == k32
+        for rep in range(2):  # twice: same bits
+            eng.conv(pk, views, out, in_slope=in_slope, out_slope=out_slope, res=res, gate=gate, res2=res2)
+            got = eng.to_nchw(out)
+            if rep:
+                assert torch.equal(got, outs[k32])
+            outs[k32] = got
+    eng.use_k32 = True
+    assert eng.read_status() == 0
+    o1, o0 = outs[True].cpu().double(), outs[False].cpu().double()
+    assert not torch.isnan(o1).any()
+    assert (o1 - want).abs().max().item() < 3e-6 * scale + 2e-7 * want.abs().max().item()
+    assert (o1 - o0).abs().max().item() < 2e-6 * scale + 2e-7 * want.abs().max().item()
+
+
+def test_k32_conv_flags_outputs_beyond_the_split_fp16_range(eng_split):
+    """The always-on range guard of the k32 kernel: an output beyond +-8188 sets DCVC_STATUS_ACT_SATURATED."""
+    eng = eng_split
+    x = torch.full((1, 32, 16, 32), 100.0)
+    w = torch.full((32, 32, 3, 3), 1.0)
+    pk = eng.pack(("k32sat",), torch.nn.Parameter(w.cuda()), torch.nn.Parameter(torch.zeros(32).cuda()), (32,), False)
+    out = eng.buf("k32/sat", 1, 16, 32, 32)
+    assert eng.read_status() == 0
+    eng.conv(pk, [to_view(eng, "k32/satin", x)], out)
+    assert eng.k32_capable(pk, 1, out, None, None, None)
+    assert eng.read_status() & 1
+    assert eng.read_status() == 0
+
+
 S16_CASES = [
     # cin segments, cout, H, W, N, ps, in_slope, out_slope, res ("f32"/"s16"/None), gate, res2, twin act ("none" = no twin), f32 out
     ((64,), 64, 40, 72, 1, False, None, 0.01, "f32", False, None, "none", True),      # partial tiles in both directions

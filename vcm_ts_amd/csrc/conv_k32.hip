@@ -1,0 +1,453 @@
+// conv_k32.hip -- split-fp16 stride-1 convolution on v_mfma_f32_16x16x32_f16 with 32-channel K chunks.
+//
+// Same operator as conv_mfma.hip's DCVC_PREC_FP16X3 path (nn.Conv2d + bias + (Leaky)ReLU + residual(s) + SE gate +
+// nn.PixelShuffle(2) + torch.cat prologue: /root/reference/DCVC_HEM/src/layers/layers.py:18-127,
+// src/models/video_net.py:74-115,165-223, src/models/video_model.py:17-128), for the layers whose input segments
+// are multiples of 32 channels -- every heavy 3x3 layer of the P- and I-picture networks.
+//
+// Why a second kernel: round 3 measured the bare loops (tools/probes/mfma_loop_probe.hip,
+// profiles/r03_mfma_loop_probe.txt): LDS fragment reads + MFMAs only, random operands, equal FLOPs and equal
+// 64 px x 64 channel tile per wave.  v_mfma_f32_16x16x32_f16 delivers 1853 TFLOP/s where v_mfma_f32_32x32x16_f16
+// delivers 1560: the chip holds 1.87 GHz on the 16x16 shape against 1.62 GHz on the 32x32 one (MI355X_MICROARCH.md
+// "DVFS give-back" item 7).  One tap of a 32-channel chunk is exactly one K step of the 16x16x32 instruction.
+//
+// GEMM view:  Out[pixel][cout] = sum_{chunk, tap, cin in chunk} In[pixel + tap][cin] * W[tap][cin][cout]
+//   M = 16 consecutive output pixels of a row, N = 16 output channels, K = 32 input channels of one tap.
+// A 256-thread workgroup owns 8 rows x 32 px x BN (= 64 or 32) channels; wave w owns rows 2w, 2w+1 as 4 M tiles
+// x BN/16 N tiles (64 accumulator registers at BN = 64).  Per 32-channel chunk the input patch with halo is staged
+// once, converted to the split form, and the filter is staged one filter ROW (KS taps) at a time:
+//   patch [PH][PW] records of 160 B: [32 x fp16 hi | 32 x fp16 lo | 32 B pad]   (the pad makes the ds_read_b128
+//         of 16 consecutive pixels conflict-free: slot = 10 px + kq (mod 16) is a bijection on each lane group)
+//   wl    [tap][hi, lo][kq 0..3][BN][8 x fp16]   packed on the host, copied linearly
+// = 54 400 + 24 576 B for 3x3 at BN = 64: two workgroups per CU.  Lane l of the MFMA holds A[pixel l & 15]
+// [k = 8 (l >> 4) + j] and B[k = 8 (l >> 4) + j][channel l & 15], j = 0..7: channels in natural order.
+// x * w ~= xh*wh + xh*wl + xl*wh in that order (hi = fp16(8 x), lo = fp16(8 x - hi); weights scaled by 64), fp32
+// accumulate, as in conv_mfma.hip.  Results are deterministic (no atomics on data) but NOT bit-identical to the
+// 32x32x16 kernel: the instruction sums 32 products per step instead of 16.  A layer is served by exactly one of the
+// two kernels for a given engine configuration, on the encoder and on the decoder side alike.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "dcvc_hip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int KC = 32;   // channels per K chunk
+constexpr int REC = 40;  // floats per pixel record of the LDS patch (160 B)
+constexpr float ACT_SCALE = 8.f;
+constexpr float WGT_SCALE = 64.f;
+constexpr float F16_MAX = 65504.f;
+constexpr float ACT_LIMIT = F16_MAX / ACT_SCALE;
+
+struct K32 {
+    const float *seg_ptr[DCVC_MAX_SEG];
+    int seg_C[DCVC_MAX_SEG];
+    int seg_cs[DCVC_MAX_SEG];
+    int nseg;
+    int H, W;  // stride 1, "same" padding: output size == input size
+    int in_act;
+    float in_slope;
+    const float *wpack;
+    const float *bpack;
+    int Cout, Cout_pad;
+    float *out;
+    int out_cs;
+    int out_act;
+    float out_slope;
+    int ps;
+    const float *res;
+    int res_cs;
+    const float *res_gate;
+    const float *res2;
+    int res2_cs;
+    int *status;
+    float *chan_partial;
+    int ntx;
+};
+
+__device__ __forceinline__ float act(float v, float slope) { return v > 0.f ? v : v * slope; }
+
+template <int KS, int NTW>
+__global__ __launch_bounds__(256, 2) void conv_k32(const K32 a) {
+    constexpr int BH = 8, BW = 32, BN = 16 * NTW;
+    constexpr int PH = BH + KS - 1, PW = BW + KS - 1, PAD = KS / 2;
+    constexpr int T = KS * KS, TPS = KS, NST = KS;  // one filter row of taps in LDS at a time
+    constexpr int EPI_LD = BN + 4;
+    constexpr int LDS_MAIN = PH * PW * REC + TPS * 8 * BN * 4, LDS_EPI = 4 * 32 * EPI_LD, LDS_RED = 4 * BN;
+    __shared__ __attribute__((aligned(16))) float lds[LDS_MAIN > LDS_EPI + LDS_RED ? LDS_MAIN : LDS_EPI + LDS_RED];
+    float *patch = lds;
+    float *wl = lds + PH * PW * REC;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nbn = a.Cout_pad / BN;
+    const int nb = blockIdx.x % nbn, tx = blockIdx.x / nbn;
+    const int x0 = tx * BW, y0 = blockIdx.y * BH, n0 = nb * BN, img = blockIdx.z;
+
+    f32x4 acc[4][NTW];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < NTW; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // M tile m of a wave: row 2 * wave + (m >> 1), pixels 16 * (m & 1) .. + 15
+    const int a_base = ((wave * 2) * PW + (lane & 15)) * REC + (lane >> 4) * 4;
+    const int b_base = ((lane >> 4) * BN + (lane & 15)) * 4;
+
+    // ---- software-pipelined main loop: a step is (32-channel chunk, filter row).  While the MFMAs of step k run,
+    // the global loads of step k+1 are in flight into registers (rp: the patch, only when the chunk changes; rw: the
+    // filter row) and are written to LDS after the barrier that ends step k.
+    constexpr int NP = (PH * PW * 8 + 255) / 256, NW = (TPS * 8 * BN + 255) / 256;
+    f32x4 rp[NP], rw[NW];
+    struct Cursor {
+        int s, c0, cg, st;
+    };
+    auto advance = [&](Cursor &k) {
+        if (++k.st == NST) {
+            k.st = 0;
+            ++k.cg;
+            k.c0 += KC;
+            if (k.c0 >= a.seg_C[k.s]) {
+                ++k.s;
+                k.c0 = 0;
+            }
+        }
+    };
+    int poff[NP];
+    unsigned inpic = 0;
+#pragma unroll
+    for (int u = 0; u < NP; ++u) {
+        const int i = tid + u * 256;
+        const int p = i >> 3;
+        const int py = p / PW, px = p - py * PW;
+        const int gy = y0 - PAD + py, gx = x0 - PAD + px;
+        const bool ok = i < PH * PW * 8 && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+        poff[u] = ok ? gy * a.W + gx : 0;
+        inpic |= (ok ? 1u : 0u) << u;
+    }
+    auto load_patch = [&](const Cursor &k) {
+        const int cs = a.seg_cs[k.s];
+        const float *sp = a.seg_ptr[k.s] + (size_t)img * a.H * a.W * cs + k.c0 + (tid & 7) * 4;
+#pragma unroll
+        for (int u = 0; u < NP; ++u) rp[u] = *(const f32x4 *)(sp + (size_t)poff[u] * cs);
+    };
+    auto store_patch = [&]() {
+#pragma unroll
+        for (int u = 0; u < NP; ++u) {
+            const int i = tid + u * 256;
+            if (i < PH * PW * 8) {
+                f32x4 v = ((inpic >> u) & 1u) ? rp[u] : (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (a.in_act) {
+                    v[0] = act(v[0], a.in_slope);
+                    v[1] = act(v[1], a.in_slope);
+                    v[2] = act(v[2], a.in_slope);
+                    v[3] = act(v[3], a.in_slope);
+                }
+                f32x4 sv = v * ACT_SCALE;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) sv[e] = __builtin_amdgcn_fmed3f(sv[e], -F16_MAX, F16_MAX);
+                const f16x4 hi = __builtin_convertvector(sv, f16x4);
+                const f16x4 lo = __builtin_convertvector(sv - __builtin_convertvector(hi, f32x4), f16x4);
+                _Float16 *rec = (_Float16 *)&patch[(i >> 3) * REC];
+                *(f16x4 *)&rec[(i & 7) * 4] = hi;
+                *(f16x4 *)&rec[32 + (i & 7) * 4] = lo;
+            }
+        }
+    };
+    auto load_w = [&](const Cursor &k) {
+        const float *wsrc = a.wpack + ((size_t)(k.cg * T + k.st * TPS) * 8) * a.Cout_pad * 4 + (size_t)n0 * 4;
+#pragma unroll
+        for (int u = 0; u < NW; ++u) {
+            const int i = tid + u * 256;
+            const int row = i / BN, col = i - row * BN;
+            if (i < TPS * 8 * BN) rw[u] = *(const f32x4 *)(wsrc + ((size_t)row * a.Cout_pad + col) * 4);
+        }
+    };
+    auto store_w = [&]() {
+#pragma unroll
+        for (int u = 0; u < NW; ++u) {
+            const int i = tid + u * 256;
+            if (i < TPS * 8 * BN) *(f32x4 *)&wl[i * 4] = rw[u];
+        }
+    };
+
+    auto mfma_step = [&](int st) __attribute__((always_inline)) {
+        const int a_st = st * PW * REC;  // filter row ky = st
+#pragma unroll
+        for (int tl = 0; tl < TPS; ++tl) {  // kx = tl
+            f16x8 ah[4], al[4], bh[NTW], bl[NTW];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const float *rec = &patch[a_base + a_st + ((m >> 1) * PW + (m & 1) * 16 + tl) * REC];
+                ah[m] = *(const f16x8 *)rec;
+                al[m] = *(const f16x8 *)(rec + 16);
+            }
+#pragma unroll
+            for (int n = 0; n < NTW; ++n) {
+                bh[n] = *(const f16x8 *)&wl[b_base + ((tl * 2 + 0) * 4 * BN + n * 16) * 4];
+                bl[n] = *(const f16x8 *)&wl[b_base + ((tl * 2 + 1) * 4 * BN + n * 16) * 4];
+            }
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int n = 0; n < NTW; ++n) {
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[m], bh[n], acc[m][n], 0, 0, 0);
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[m], bl[n], acc[m][n], 0, 0, 0);
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[m], bh[n], acc[m][n], 0, 0, 0);
+                }
+        }
+    };
+
+    // The patch of chunk c+1 is requested right after chunk c's patch has left the staging registers, a whole chunk
+    // (KS steps) ahead of its use instead of one step: the HBM latency of the only operand that comes from beyond L2
+    // hides behind three steps of MFMAs (on all-zero operands, i.e. at the full clock, this kernel takes 85 % of its
+    // random-data time -- tools/conv_data_probe.py: stalls, not board power, are the larger part of what bounds it).
+    Cursor cur = {0, 0, 0, 0};
+    load_patch(cur);
+    load_w(cur);
+    while (cur.s < a.nseg) {
+        __syncthreads();  // every wave is done reading the previous step's LDS
+        if (cur.st == 0) store_patch();
+        store_w();
+        __syncthreads();
+        Cursor nxt = cur;
+        advance(nxt);
+        if (cur.st == 0) {
+            Cursor nc = cur;
+            nc.c0 += KC;
+            if (nc.c0 >= a.seg_C[nc.s]) {
+                ++nc.s;
+                nc.c0 = 0;
+            }
+            if (nc.s < a.nseg) load_patch(nc);
+        }
+        if (nxt.s < a.nseg) load_w(nxt);
+        mfma_step(cur.st);
+        cur = nxt;
+    }
+
+    // ---- epilogue: bias, activation, (gated) residual(s), NHWC or pixel-shuffled store.  The MFMA leaves a channel
+    // per lane and 4 pixels in registers; a per-wave transpose through LDS turns that into 4 consecutive channels per
+    // lane, so every global access is a 16-byte one, and all residual loads of the wave's rows are in flight before
+    // the first store (res may alias out: each element is read and written by the same lane).
+    const int Cq = a.Cout >> 2;
+    const int Cfin = a.ps ? Cq : a.Cout;
+    const int Ho = a.ps ? a.H * 2 : a.H, Wo = a.ps ? a.W * 2 : a.W;
+    constexpr float inv_scale = 1.f / (ACT_SCALE * WGT_SCALE);
+    constexpr int LPP = BN / 4, PPI = 64 / LPP, NIT = 32 / PPI;
+    float *epi = lds + wave * 32 * EPI_LD;
+    const int c4 = (lane % LPP) * 4, pl = lane / LPP;
+    const int ch = n0 + c4;
+    const bool ch_ok = ch < a.Cout;
+    int dy = 0, dx = 0, cf = ch;
+    if (a.ps) {
+        const int sub = ch / Cq;
+        cf = ch - sub * Cq;
+        dy = sub >> 1;
+        dx = sub & 1;
+    }
+    f32x4 bias = {0.f, 0.f, 0.f, 0.f}, gate = {1.f, 1.f, 1.f, 1.f};
+    if (ch_ok) {
+        bias = *(const f32x4 *)&a.bpack[ch];
+        if (a.res_gate) gate = *(const f32x4 *)&a.res_gate[(size_t)img * Cfin + cf];
+    }
+    __syncthreads();  // main loop's LDS reads are done in every wave
+    size_t pix[2][NIT];
+    bool ok[2][NIT];
+    f32x4 rv[2][NIT], rv2[2][NIT];
+    f32x4 csum = {0.f, 0.f, 0.f, 0.f};  // this lane's 4 channels summed over its pixels (SE squeeze)
+    float vmax = 0.f;                   // largest |output| this lane stores (range guard)
+#pragma unroll
+    for (int mr = 0; mr < 2; ++mr) {
+        const int oy = y0 + wave * 2 + mr;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int ox = x0 + it * PPI + pl;
+            ok[mr][it] = ch_ok && oy < a.H && ox < a.W;
+            pix[mr][it] = a.ps ? ((size_t)(img * Ho + 2 * oy + dy) * Wo + 2 * ox + dx) : ((size_t)(img * Ho + oy) * Wo + ox);
+            rv[mr][it] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            rv2[mr][it] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (ok[mr][it] && a.res) rv[mr][it] = *(const f32x4 *)&a.res[pix[mr][it] * a.res_cs + cf];
+            if (ok[mr][it] && a.res2) rv2[mr][it] = *(const f32x4 *)&a.res2[pix[mr][it] * a.res2_cs + cf];
+        }
+    }
+#pragma unroll
+    for (int mr = 0; mr < 2; ++mr) {
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+            for (int n = 0; n < NTW; ++n)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    epi[(hf * 16 + (lane >> 4) * 4 + r) * EPI_LD + n * 16 + (lane & 15)] = acc[mr * 2 + hf][n][r];
+        // the transpose tile is private to this wave and a wave's LDS operations execute in order: draining its own
+        // ds_writes is all the synchronisation the reads below need
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            f32x4 v = *(const f32x4 *)&epi[(it * PPI + pl) * EPI_LD + c4];
+            v = v * inv_scale + bias;
+            if (a.out_act == 1) {
+                v[0] = act(v[0], a.out_slope);
+                v[1] = act(v[1], a.out_slope);
+                v[2] = act(v[2], a.out_slope);
+                v[3] = act(v[3], a.out_slope);
+            } else if (a.out_act == 2) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = fminf(fmaxf(v[e], 0.f), 1.f);
+            }
+            if (a.res) {
+                if (a.res_gate) {  // explicit fma: the same rounding in every kernel that applies the SE gate
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaf(rv[mr][it][e], gate[e], v[e]);
+                } else {
+                    v = v + rv[mr][it];
+                }
+            }
+            if (a.res2) v = rv2[mr][it] + v;
+            if (ok[mr][it]) {
+                if (a.chan_partial) csum += v;
+                // range guard, always on (two v_max3_f32 per 4 outputs): an output beyond +-8188 would be clamped by
+                // a split-fp16 consumer.  An infinity is caught here; a NaN can only follow one.
+                vmax = fmaxf(vmax, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+                *(f32x4 *)&a.out[pix[mr][it] * a.out_cs + cf] = v;
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // reads done before the tile is rewritten
+    }
+    if (a.status && !(vmax <= ACT_LIMIT)) atomicOr(a.status, DCVC_STATUS_ACT_SATURATED);
+    if (a.chan_partial) {
+        // SELayer's AdaptiveAvgPool (video_net.py:149-162) rides on the producing convolution: lanes with the same
+        // channel quad are LPP apart -> butterfly inside the wave, the four waves through LDS, one partial row per
+        // workgroup; dcvc_channel_mean_finish adds the rows in a fixed order (no atomics: encoder and decoder derive
+        // bit-identical gates)
+#pragma unroll
+        for (int off = LPP; off < 64; off <<= 1)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) csum[e] += __shfl_xor(csum[e], off);
+        float *red = lds + LDS_EPI;
+        if (lane < LPP) *(f32x4 *)&red[wave * BN + c4] = csum;
+        __syncthreads();
+        if (tid < BN && n0 + tid < a.Cout_pad) {
+            const float s = ((red[tid] + red[BN + tid]) + red[2 * BN + tid]) + red[3 * BN + tid];
+            const size_t part = (size_t)img * (gridDim.y * a.ntx) + (size_t)blockIdx.y * a.ntx + tx;
+            a.chan_partial[part * a.Cout_pad + n0 + tid] = s;
+        }
+    }
+}
+
+template <int KS, int NTW>
+int launch(K32 &k, int N, hipStream_t st) {
+    constexpr int BN = 16 * NTW;
+    k.ntx = (k.W + 31) / 32;
+    dim3 grid((unsigned)(k.ntx * (k.Cout_pad / BN)), (unsigned)((k.H + 7) / 8), (unsigned)N);
+    hipLaunchKernelGGL((conv_k32<KS, NTW>), grid, dim3(256), 0, st, k);
+    return hipGetLastError() == hipSuccess ? DCVC_OK : DCVC_E_LAUNCH;
+}
+
+inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+inline bool aligned16(const void *p, int cs) { return p == nullptr || ((((uintptr_t)p) & 15) == 0 && (cs & 3) == 0); }
+
+}  // namespace
+
+extern "C" int64_t dcvc_conv_k32_pack_bytes(int32_t Cout, int32_t ks, int32_t nseg, const int32_t *seg_C, int32_t *cout_pad) {
+    if (Cout <= 0 || nseg <= 0 || nseg > DCVC_MAX_SEG || (ks != 1 && ks != 3)) return DCVC_E_ARG;
+    int chunks = 0;
+    for (int s = 0; s < nseg; ++s) {
+        if (seg_C[s] <= 0 || seg_C[s] % KC) return DCVC_E_ARG;
+        chunks += seg_C[s] / KC;
+    }
+    const int cp = round_up(Cout, 32);
+    if (cout_pad) *cout_pad = cp;
+    return (int64_t)chunks * ks * ks * 8 * cp * 16;
+}
+
+// wpack as 16-byte entries: entry[((chunk * T + tap) * 2 + hl) * 4 + kq][n'] = 8 fp16: w[n][cin = 32 chunk + 8 kq + j][tap]
+// (hl 0: hi, 1: lo of 64 w), n' = n, or with pixel shuffle n' = (n % 4) * (Cout / 4) + n / 4 (sub-pixel planes contiguous).
+extern "C" int dcvc_conv_k32_pack_weights(const float *w, const float *b, int32_t Cout, int32_t ks, int32_t nseg,
+                                          const int32_t *seg_C, int32_t pixel_shuffle, void *wpack, float *bpack) {
+    int32_t cp = 0;
+    const int64_t total = dcvc_conv_k32_pack_bytes(Cout, ks, nseg, seg_C, &cp);
+    if (total < 0 || (pixel_shuffle && (Cout & 3))) return DCVC_E_ARG;
+    const int T = ks * ks;
+    int Cin = 0;
+    for (int s = 0; s < nseg; ++s) Cin += seg_C[s];
+    memset(wpack, 0, (size_t)total);
+    memset(bpack, 0, (size_t)cp * sizeof(float));
+    _Float16 *base = (_Float16 *)wpack;
+    const int Cq = Cout / 4;
+    bool clamped = false;
+    for (int c = 0; c < Cin; ++c) {  // segments are multiples of 32: chunk boundaries never straddle one
+        const int cg = c / KC, kq = (c % KC) >> 3, j = c & 7;
+        for (int t = 0; t < T; ++t)
+            for (int n = 0; n < Cout; ++n) {
+                const int np = pixel_shuffle ? (n & 3) * Cq + (n >> 2) : n;
+                float sv = w[((size_t)n * Cin + c) * T + t] * WGT_SCALE;
+                if (!(fabsf(sv) <= F16_MAX)) {
+                    clamped = true;
+                    sv = sv > 0.f ? F16_MAX : -F16_MAX;
+                }
+                const _Float16 hi = (_Float16)sv, lo = (_Float16)(sv - (float)hi);
+                base[(((((size_t)cg * T + t) * 2 + 0) * 4 + kq) * cp + np) * 8 + j] = hi;
+                base[(((((size_t)cg * T + t) * 2 + 1) * 4 + kq) * cp + np) * 8 + j] = lo;
+            }
+    }
+    for (int n = 0; n < Cout; ++n) {
+        const int np = pixel_shuffle ? (n & 3) * Cq + (n >> 2) : n;
+        bpack[np] = b ? b[n] : 0.f;
+    }
+    return clamped ? DCVC_E_RANGE : DCVC_OK;
+}
+
+extern "C" int dcvc_conv2d_k32(const dcvc_conv_args *a, void *stream) {
+    if (!a || a->nseg < 1 || a->nseg > DCVC_MAX_SEG || !a->out || !a->wpack || !a->bpack) return DCVC_E_ARG;
+    if (a->stride != 1 || (a->ks != 1 && a->ks != 3) || a->precision != DCVC_PREC_FP16X3) return DCVC_E_ARG;
+    if (a->Cout_pad % 32 || a->Cout > a->Cout_pad || (a->pixel_shuffle && (a->Cout & 3))) return DCVC_E_ARG;
+    K32 k;
+    memset(&k, 0, sizeof(k));
+    for (int s = 0; s < a->nseg; ++s) {
+        if (!a->seg[s].ptr || a->seg[s].C <= 0 || a->seg[s].C % KC || (a->seg[s].cs & 3) || a->seg[s].cs < a->seg[s].C ||
+            ((uintptr_t)a->seg[s].ptr & 15))
+            return DCVC_E_ARG;
+        k.seg_ptr[s] = a->seg[s].ptr;
+        k.seg_C[s] = a->seg[s].C;
+        k.seg_cs[s] = a->seg[s].cs;
+    }
+    k.nseg = a->nseg;
+    k.H = a->Hin;
+    k.W = a->Win;
+    k.in_act = a->in_act;
+    k.in_slope = a->in_slope;
+    k.wpack = a->wpack;
+    k.bpack = a->bpack;
+    k.Cout = a->Cout;
+    k.Cout_pad = a->Cout_pad;
+    k.out = a->out;
+    k.out_cs = a->out_cs;
+    k.out_act = a->out_act;
+    k.out_slope = a->out_slope;
+    k.ps = a->pixel_shuffle;
+    k.res = a->res;
+    k.res_cs = a->res_cs;
+    k.res_gate = a->res_gate;
+    k.res2 = a->res2;
+    k.res2_cs = a->res2_cs;
+    k.status = a->status;
+    k.chan_partial = a->chan_partial;
+    const int cfin = a->pixel_shuffle ? a->Cout / 4 : a->Cout;
+    // this kernel has the 16-byte epilogue only (every layer it is meant for qualifies); others stay on dcvc_conv2d
+    if ((cfin % 4) || !aligned16(a->out, a->out_cs) || !aligned16(a->res, a->res_cs) || !aligned16(a->res2, a->res2_cs) ||
+        (a->res_gate && (((uintptr_t)a->res_gate) & 15)))
+        return DCVC_E_ARG;
+    if (a->chan_partial && a->pixel_shuffle) return DCVC_E_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const bool wide = (a->Cout_pad % 64) == 0;
+    if (a->ks == 3) return wide ? launch<3, 4>(k, a->N, st) : launch<3, 2>(k, a->N, st);
+    return wide ? launch<1, 4>(k, a->N, st) : launch<1, 2>(k, a->N, st);
+}

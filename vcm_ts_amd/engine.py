@@ -94,7 +94,7 @@ class View:
 
 class PackedConv:
     __slots__ = ("w", "b", "ks", "Cout", "Cout_pad", "seg_C", "ps", "version", "precision", "weight", "bias",
-                 "cin_slice", "key", "s16", "small", "host", "job")
+                 "cin_slice", "key", "s16", "small", "k32", "host", "job")
 
 
 class Engine:
@@ -121,6 +121,9 @@ class Engine:
         self._status = None  # device status word of the split-fp16 kernels (saturation flag)
         self.use_s16 = os.environ.get("DCVC_S16", "1") != "0"
         self.use_small = os.environ.get("DCVC_SMALL", "1") != "0"   # dcvc_conv2d_small for <= 16 output channels
+        # dcvc_conv2d_k32 (16x16x32 MFMA, 32-channel chunks) for the stride-1 3x3 / 1x1 layers it covers; DCVC_K32=0
+        # keeps them on dcvc_conv2d (developer A/B switch: an encoder and its decoder must use the same setting)
+        self.use_k32 = os.environ.get("DCVC_K32", "1") != "0"
         # fp16x3 mode clamps |activation| > 8188 on load; with range_check on, every convolution launch also
         # flags outputs beyond that magnitude in the status word (check_status() raises).  Off by default: it
         # costs VALU work in the epilogue; bench.py and the tests turn it on for a checked pass.
@@ -444,6 +447,42 @@ class Engine:
         pk.small = q
         return q
 
+    def pack_k32(self, pk: PackedConv) -> PackedConv:
+        """The same layer packed for dcvc_conv2d_k32 (32-channel chunks), cached beside the other packing."""
+        q = getattr(pk, "k32", None)
+        if q is not None and q.version == pk.version:
+            return q
+        w = pk.weight.detach().float().cpu()
+        if pk.cin_slice is not None:
+            w = w[:, pk.cin_slice[0] : pk.cin_slice[1]]
+        w = w.contiguous().numpy()
+        b = None if pk.bias is None else pk.bias.detach().float().cpu().contiguous().numpy()
+        segs = (C.c_int32 * len(pk.seg_C))(*pk.seg_C)
+        cpad = C.c_int32()
+        n = self.L.dcvc_conv_k32_pack_bytes(pk.Cout, pk.ks, len(pk.seg_C), segs, C.byref(cpad))
+        if n < 0:
+            raise lib.KernelError(f"conv_k32_pack_bytes({pk.key})")
+        wp = np.empty(n // 4, np.float32)
+        bp = np.empty(cpad.value, np.float32)
+        lib.check(self.L.dcvc_conv_k32_pack_weights(w.ctypes.data, None if b is None else b.ctypes.data, pk.Cout, pk.ks,
+                                                    len(pk.seg_C), segs, int(pk.ps), wp.ctypes.data, bp.ctypes.data),
+                  f"conv_k32_pack_weights({pk.key}) [status -3: a |weight| >= 1023.5 does not fit split fp16, use precision='fp32']")
+        q = PackedConv()
+        q.w, q.b = torch.from_numpy(wp).to(self.device), torch.from_numpy(bp).to(self.device)
+        q.ks, q.Cout, q.Cout_pad, q.seg_C, q.ps, q.version, q.key = pk.ks, pk.Cout, cpad.value, pk.seg_C, pk.ps, pk.version, pk.key
+        pk.k32 = q
+        return q
+
+    def k32_capable(self, pk: PackedConv, stride, out: View, res, res2, gate) -> bool:
+        """Layers dcvc_conv2d_k32 covers: fp16x3, 3x3, stride 1, every input segment a multiple of 32 channels,
+        16-byte-addressable epilogue (4-channel groups of out / residuals)."""
+        if not (self.precision == "fp16x3" and self.tape is None and self.use_k32 and getattr(pk, "host", False)):
+            return False
+        cfin = pk.Cout // 4 if pk.ps else pk.Cout
+        al = lambda v: v is None or (v.ptr % 16 == 0 and v.cs % 4 == 0)
+        return (pk.ks == 3 and stride == 1 and all(c % 32 == 0 for c in pk.seg_C) and cfin % 4 == 0
+                and al(out) and al(res) and al(res2) and (gate is None or gate.data_ptr() % 16 == 0))
+
     def small_capable(self, pk: PackedConv, stride, gate, res2, chan_partial) -> bool:
         """Layers dcvc_conv2d_small covers: <= 16 output channels, 3x3 / 7x7, stride 1, plain epilogue, fp16x3."""
         return (self.precision == "fp16x3" and self.tape is None and self.use_small and getattr(pk, "host", False)
@@ -550,7 +589,8 @@ class Engine:
         a.nseg, a.N, a.Hin, a.Win = len(srcs), s0.N, s0.H, s0.W
         a.in_act, a.in_slope = (0, 0.0) if in_slope is None else (1, in_slope)
         small = self.small_capable(pk, stride, gate, res2, chan_partial)
-        wq = self.pack_small(pk) if small else pk
+        k32 = not small and self.k32_capable(pk, stride, out, res, res2, gate)
+        wq = self.pack_small(pk) if small else (self.pack_k32(pk) if k32 else pk)
         a.wpack, a.bpack = wq.w.data_ptr(), wq.b.data_ptr()
         a.ks, a.stride, a.Cout, a.Cout_pad = pk.ks, stride, pk.Cout, wq.Cout_pad
         pad = pk.ks // 2
@@ -571,11 +611,12 @@ class Engine:
         if res2 is not None:
             assert (res2.N, res2.H, res2.W, res2.C) == (out.N, out.H, out.W, out.C)
             a.res2, a.res2_cs = res2.ptr, res2.cs
-        if self.range_check and self.precision == "fp16x3":
+        if (self.range_check or k32) and self.precision == "fp16x3":  # the k32 kernel's guard is cheap: always on
             a.status = self.status_word().data_ptr()
         if chan_partial is not None:
             a.chan_partial = chan_partial.data_ptr()
-        fn, what = (self.L.dcvc_conv2d_small, "conv2d_small") if small else (self.L.dcvc_conv2d, "conv2d")
+        fn, what = (self.L.dcvc_conv2d_small, "conv2d_small") if small else (
+            (self.L.dcvc_conv2d_k32, "conv2d_k32") if k32 else (self.L.dcvc_conv2d, "conv2d"))
         note = ""
         if self.profile_detail is not None:  # per-launch listing of tools/in_pipeline_detail.py: layer name and epilogue flags
             note = (f"{pk.key[0][1] if isinstance(pk.key[0], tuple) and len(pk.key[0]) > 1 else pk.key[0]}"
@@ -583,7 +624,7 @@ class Engine:
                     f" res={None if res is None else res.cs} gate={gate is not None} res2={None if res2 is None else res2.cs}"
                     f" chan_sums={chan_partial is not None}")
         self._launch_conv(lambda: lib.check(fn(C.byref(a), self.stream()), what), pk, s0, Ho, Wo, stride, res, res2,
-                          "small" if small else "", note)
+                          "small" if small else ("k32" if k32 else ""), note)
         self.calls += 1
         self._rec("conv", pk, tuple(srcs), out, stride, in_slope, out_slope, res, gate, res2)
         return out

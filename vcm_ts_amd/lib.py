@@ -149,6 +149,8 @@ _SIGS = {
     "dcvc_conv_pack_weights": [vp, vp, i32, i32, i32, vp, i32, i32, vp, vp],
     "dcvc_conv2d_small": [C.POINTER(ConvArgs), vp],
     "dcvc_conv_small_pack_weights": [vp, vp, i32, i32, i32, vp, vp, vp],
+    "dcvc_conv2d_k32": [C.POINTER(ConvArgs), vp],
+    "dcvc_conv_k32_pack_weights": [vp, vp, i32, i32, i32, vp, i32, vp, vp],
     "dcvc_conv2d_s16": [C.POINTER(ConvS16Args), vp],
     "dcvc_conv_s16_pack_weights": [vp, vp, i32, i32, i32, vp, i32, vp, vp],
     "dcvc_s16_pack": [vp, i32, vp, i32, i32, i64, i32, i32, f32, vp, vp],
@@ -203,7 +205,7 @@ _SIGS = {
     "dcvc_drans_build_lut": [vp, i32, i32, vp, vp],
 }
 
-HIP_SYMBOLS = sorted(list(_SIGS) + ["dcvc_cdf_table_cols", "dcvc_conv_pack_size", "dcvc_conv_small_pack_bytes", "dcvc_conv_s16_pack_bytes", "dcvc_conv_chan_partial_parts", "dcvc_hip_version", "dcvc_conv_wgrad_scratch_min",
+HIP_SYMBOLS = sorted(list(_SIGS) + ["dcvc_cdf_table_cols", "dcvc_conv_pack_size", "dcvc_conv_small_pack_bytes", "dcvc_conv_s16_pack_bytes", "dcvc_conv_k32_pack_bytes", "dcvc_conv_chan_partial_parts", "dcvc_hip_version", "dcvc_conv_wgrad_scratch_min",
                                     "dcvc_drans_default_lanes", "dcvc_drans_scratch_words"])
 RANS_SYMBOLS = [
     "dcvc_rans_encoder_create", "dcvc_rans_encoder_destroy", "dcvc_rans_encoder_reset",
@@ -232,6 +234,8 @@ def hip():
         L.dcvc_conv_small_pack_bytes.restype = i64
         L.dcvc_conv_s16_pack_bytes.argtypes = [i32, i32, i32, vp, C.POINTER(i32)]
         L.dcvc_conv_s16_pack_bytes.restype = i64
+        L.dcvc_conv_k32_pack_bytes.argtypes = [i32, i32, i32, vp, C.POINTER(i32)]
+        L.dcvc_conv_k32_pack_bytes.restype = i64
         L.dcvc_hip_version.restype = C.c_char_p
         L.dcvc_conv_wgrad_scratch_min.argtypes = [i32, i32, i32]
         L.dcvc_conv_wgrad_scratch_min.restype = i64
