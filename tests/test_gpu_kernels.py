@@ -204,29 +204,23 @@ def test_k32_conv_matches_fp64_and_the_32x32_kernel(eng_split, case):
         v = to_view(eng, f"k32/in{i}", x[:, c0 : c0 + c], cs=in_cs)
         views.append(v)
         c0 += c
-    import os
-
     outs = {}
     try:
-        for mode in ("persistent", "simple", "32x32"):
-            eng.use_k32 = mode != "32x32"
-            os.environ["DCVC_K32_PERSISTENT"] = "2" if mode == "persistent" else "0"  # (read per launch by the library)
-            out = eng.buf(f"k32/out_{mode}", N, want.shape[2], want.shape[3], want.shape[1])
+        for k32 in (True, False):
+            eng.use_k32 = k32
+            out = eng.buf(f"k32/out{int(k32)}", N, want.shape[2], want.shape[3], want.shape[1])
             out.base.fill_(float("nan"))
-            assert eng.k32_capable(pk, 1, out, res, res2, gate) == eng.use_k32
+            assert eng.k32_capable(pk, 1, out, res, res2, gate) == k32
             for rep in range(2):  # twice: same bits
                 eng.conv(pk, views, out, in_slope=in_slope, out_slope=out_slope, res=res, gate=gate, res2=res2)
                 got = eng.to_nchw(out)
                 if rep:
-                    assert torch.equal(got, outs[mode])
-                outs[mode] = got
+                    assert torch.equal(got, outs[k32])
+                outs[k32] = got
     finally:
         eng.use_k32 = True
-        os.environ.pop("DCVC_K32_PERSISTENT", None)
     assert eng.read_status() == 0
-    # the persistent and the simple form of the 16x16x32 kernel: the same products in the same order
-    assert torch.equal(outs["persistent"], outs["simple"])
-    o1, o0 = outs["persistent"].cpu().double(), outs["32x32"].cpu().double()
+    o1, o0 = outs[True].cpu().double(), outs[False].cpu().double()
     assert not torch.isnan(o1).any()
     assert (o1 - want).abs().max().item() < 3e-6 * scale + 2e-7 * want.abs().max().item()
     assert (o1 - o0).abs().max().item() < 2e-6 * scale + 2e-7 * want.abs().max().item()
@@ -547,13 +541,7 @@ def test_fused_se_squeeze_matches_mean_of_the_output(eng, eng_split, cout, H, W,
     w = torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(cin * 9)
     b = torch.randn(cout, generator=g)
     w1, w2 = torch.randn(max(cout // 16, 1), cout, generator=g), torch.randn(cout, max(cout // 16, 1), generator=g)
-    import os
-
-    for e, persistent in ((eng, None), (eng_split, "0"), (eng_split, "2")):  # (the k32 kernel's simple / persistent form)
-        if persistent is not None:
-            os.environ["DCVC_K32_PERSISTENT"] = persistent
-        else:
-            os.environ.pop("DCVC_K32_PERSISTENT", None)
+    for e in (eng, eng_split):
         pk = e.pack(("sq", cout, H, stride), torch.nn.Parameter(w.cuda()), torch.nn.Parameter(b.cuda()), (cin,), False)
         xin = to_view(e, "sq/in", x)
         Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
@@ -568,7 +556,6 @@ def test_fused_se_squeeze_matches_mean_of_the_output(eng, eng_split, cout, H, W,
                                    atol=2e-6)
         gate_sep = e.se_gate("sq/s", out, w1.cuda(), w2.cuda())
         torch.testing.assert_close(gate_fused, gate_sep, rtol=1e-5, atol=1e-6)
-    os.environ.pop("DCVC_K32_PERSISTENT", None)
 
 
 def test_build_indexes_bit_exact_against_reference_planes(eng):
