@@ -129,7 +129,7 @@ int dcvc_conv2d(const dcvc_conv_args *a, void *stream);
  * video_model.py:115-128): 16-pixel x 16-channel tiles on v_mfma_f32_16x16x32_f16 whose 32-deep K carries the
  * hi/lo operand split (vcm_ts_amd/csrc/conv_small.hip), instead of padding the channels to 32.  Same
  * dcvc_conv_args, restricted to ks 3 or 7, stride 1, no pixel shuffle / gate / res2 / chan_partial; weights
- * from dcvc_conv_small_pack_weights (HOST; DCVC_E_RANGE as dcvc_conv_s16_pack_weights). */
+ * from dcvc_conv_small_pack_weights (HOST; DCVC_E_RANGE as dcvc_conv_k32_pack_weights). */
 int64_t dcvc_conv_small_pack_bytes(int32_t Cout, int32_t ks, int32_t nseg, const int32_t *seg_C);
 int dcvc_conv_small_pack_weights(const float *w, const float *b, int32_t Cout, int32_t ks, int32_t nseg,
                                  const int32_t *seg_C, void *wpack, float *bpack);
@@ -139,8 +139,8 @@ int dcvc_conv2d_small(const dcvc_conv_args *a, void *stream);
  * The same operator as dcvc_conv2d(DCVC_PREC_FP16X3) for stride-1 1x1 / 3x3 layers whose input segments are all
  * multiples of 32 channels, on v_mfma_f32_16x16x32_f16 (vcm_ts_amd/csrc/conv_k32.hip): one tap of a 32-channel chunk
  * is one K step.  Measured on MI355X the 16x16x32 shape sustains 1.19x the FLOP/s of 32x32x16 in the bare
- * fragment-read + MFMA loop (profiles/r03_mfma_loop_probe.txt).  Same dcvc_conv_args (precision must be
- * DCVC_PREC_FP16X3, stride 1, 16-byte-aligned epilogue: (Cout or Cout/4 with pixel shuffle) % 4 == 0 and aligned
+ * fragment-read + MFMA loop (profiles/r03_mfma_loop_probe.txt).  Same argument struct; precision must be
+ * DCVC_PREC_FP16X3, stride 1, 16-byte-aligned epilogue ((Cout or Cout/4 with pixel shuffle) % 4 == 0 and aligned
  * out / res / res2); `status` is cheap here (two VALU per four outputs) and meant to be always passed.  Weights from
  * dcvc_conv_k32_pack_weights (HOST; returns DCVC_E_RANGE with the buffers written, clamped, when a |weight| >= 1023.5).
  * Deterministic, but not bit-identical to dcvc_conv2d: the instruction sums 32 products per step instead of 16. */
@@ -148,60 +148,6 @@ int64_t dcvc_conv_k32_pack_bytes(int32_t Cout, int32_t ks, int32_t nseg, const i
 int dcvc_conv_k32_pack_weights(const float *w, const float *b, int32_t Cout, int32_t ks, int32_t nseg,
                                const int32_t *seg_C, int32_t pixel_shuffle, void *wpack, float *bpack);
 int dcvc_conv2d_k32(const dcvc_conv_args *a, void *stream);
-
-/* ---- pre-split activations ("S16") --------------------------------------------------------
- * The fast form of DCVC_PREC_FP16X3 for 3x3 stride-1 layers whose inputs were produced by another
- * convolution (vcm_ts_amd/csrc/conv_s16.hip).  An S16 tensor of C channels (C % 16 == 0) is PLANAR in
- * 16-channel chunks: element (n, c, y, x) lives in the 64-byte record
- *     base + ((n * cs/16 + c/16) * H*W + y*W + x) * 64 = [16 x fp16 hi | 16 x fp16 lo]
- * (cs = channels of the underlying buffer, cs % 16 == 0; a channel slice is a run of planes; base
- * 64-byte aligned; same size in bytes as the fp32 tensor) with hi = fp16(8 v), lo = fp16(8 v - hi):
- * exactly the operand split dcvc_conv2d performs on load, done once by the producer instead of by
- * every consumer, in a layout where a patch row of one chunk is contiguous.  Same products, same
- * accumulation order: results are bit-identical to dcvc_conv2d(DCVC_PREC_FP16X3) on the fp32 tensor. */
-#define DCVC_FMT_F32 0
-#define DCVC_FMT_S16 1
-
-typedef struct {
-    dcvc_seg seg[DCVC_MAX_SEG];  /* S16 inputs, walked in torch.cat order; ptr is the S16 buffer */
-    int32_t nseg;
-    int32_t N, H, W;             /* stride 1, padding 1: output size == input size */
-    const void *wpack;           /* dcvc_conv_s16_pack_weights */
-    const float *bpack;
-    int32_t ks;                  /* 3 */
-    int32_t Cout;                /* % 16 == 0 (and (Cout/4) % 16 == 0 with pixel_shuffle) */
-    int32_t Cout_pad;            /* as returned by dcvc_conv_s16_pack_bytes */
-    /* result = res2 + (act(conv + bias) + res * gate), as dcvc_conv2d; written to either or both of */
-    float *out;                  /* fp32 NHWC (out_cs), or NULL */
-    int32_t out_cs;
-    int32_t out_act;             /* 0 none, 1 LeakyReLU(out_slope), 2 clamp [0,1] */
-    float out_slope;
-    void *out16;                 /* S16 tensor (out16_cs) holding act16(result), or NULL */
-    int32_t out16_cs;
-    int32_t out16_act;           /* 0: the result itself; 1: LeakyReLU(out16_slope)(result), i.e. the NEXT layer's
-                                    input activation (video_net.py:82-95) applied by the producer */
-    float out16_slope;
-    int32_t pixel_shuffle;
-    const void *res;             /* optional residual, fp32 NHWC or S16 per res_fmt (may alias the same-format output) */
-    int32_t res_cs;
-    int32_t res_fmt;
-    const float *res_gate;
-    const void *res2;
-    int32_t res2_cs;
-    int32_t res2_fmt;
-    int32_t *status;             /* optional device word, OR-ed with DCVC_STATUS_* */
-} dcvc_conv_s16_args;
-
-int64_t dcvc_conv_s16_pack_bytes(int32_t Cout, int32_t ks, int32_t nseg, const int32_t *seg_C, int32_t *cout_pad);
-/* HOST function; returns DCVC_E_RANGE (buffers still written, clamped) when a weight is out of range */
-int dcvc_conv_s16_pack_weights(const float *w, const float *b, int32_t Cout, int32_t ks, int32_t nseg,
-                               const int32_t *seg_C, int32_t pixel_shuffle, void *wpack, float *bpack);
-int dcvc_conv2d_s16(const dcvc_conv_s16_args *a, void *stream);
-/* fp32 NHWC -> S16 (optionally through LeakyReLU(slope)) and back; for tensors no convolution produced */
-int dcvc_s16_pack(const float *src, int32_t src_cs, void *out, int32_t out_cs, int32_t N, int64_t HW, int32_t C, int32_t act,
-                  float slope, int32_t *status, void *stream);
-int dcvc_s16_unpack(const void *src, int32_t src_cs, float *out, int32_t out_cs, int32_t N, int64_t HW, int32_t C,
-                    void *stream);
 
 /* ---- resampling ------------------------------------------------------------------------ */
 /* out(n,y,x,c) = bilinear(src(n,.,.,c), x + flow(n,y,x,0), y + flow(n,y,x,1)), border clamp */

@@ -160,6 +160,12 @@ K32_CASES = [
     ((96,), 144, 17, 33, 1, False, None, "clamp01", False, False, False, None),  # Cout padded to 160, clamp
     ((192, 192, 96), 384, 9, 20, 1, False, None, 0.2, False, False, False, None),  # three segments, 15 chunks
     ((64, 64), 64, 8, 32, 1, False, None, None, False, False, False, None),   # exactly one tile
+    # 1x1 layers (a 13th field: kernel size)
+    ((64,), 64, 40, 72, 1, False, None, None, False, False, False, None, 1),    # feature_adaptor_P
+    ((32, 32), 64, 33, 50, 2, False, None, None, True, True, False, None, 1),   # SE block's up_dim: gated residual, two segments
+    ((64,), 32, 16, 40, 1, False, None, None, True, True, False, None, 1),      # 32-column variant
+    ((128,), 256, 18, 34, 1, True, None, None, False, False, False, None, 1),   # PixelShuffle upsampler
+    ((64,), 256, 17, 30, 1, True, None, 0.01, False, False, False, None, 1),    # subpel_conv + LeakyReLU
 ]
 
 
@@ -168,17 +174,19 @@ def test_k32_conv_matches_fp64_and_the_32x32_kernel(eng_split, case):
     """dcvc_conv2d_k32 (v_mfma_f32_16x16x32_f16, 32-channel chunks, conv_k32.hip) against an fp64 reference within the
     split-fp16 bound of test_split_fp16_conv_matches_fp64, and against conv_mfma (32x32x16) on the same layer: same
     operand values, another grouping of the sum -- fp32 rounding apart.  Both kernels are deterministic."""
-    segs, cout, H, W, N, ps, in_slope, out_slope, use_res, use_gate, use_res2, in_cs = case
+    segs, cout, H, W, N, ps, in_slope, out_slope, use_res, use_gate, use_res2, in_cs = case[:12]
+    ks = case[12] if len(case) > 12 else 3
     eng = eng_split
+    eng.k32_sizes = (1, 3)  # (1x1 layers are not routed to this kernel by default; the kernel covers them)
     g = torch.Generator().manual_seed(K32_CASES.index(case) + 90)
     cin = sum(segs)
     mag = torch.tensor([1e-3, 1.0, 20.0])[torch.randint(0, 3, (N, cin, 1, 1), generator=g)]
     x = torch.randn(N, cin, H, W, generator=g) * mag
-    w = torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(cin * 9)
+    w = torch.randn(cout, cin, ks, ks, generator=g) / math.sqrt(cin * ks * ks)
     b = torch.randn(cout, generator=g) * 0.1
     xin = x.double() if in_slope is None else F.leaky_relu(x.double(), in_slope)
-    want = F.conv2d(xin, w.double(), b.double(), padding=1)
-    scale = F.conv2d(xin.abs(), w.double().abs(), None, padding=1).max().item()
+    want = F.conv2d(xin, w.double(), b.double(), padding=ks // 2)
+    scale = F.conv2d(xin.abs(), w.double().abs(), None, padding=ks // 2).max().item()
     if out_slope == "clamp01":
         want = want.clamp(0, 1)
     elif out_slope is not None:
@@ -219,6 +227,7 @@ def test_k32_conv_matches_fp64_and_the_32x32_kernel(eng_split, case):
                 outs[k32] = got
     finally:
         eng.use_k32 = True
+        eng.k32_sizes = (3,)
     assert eng.read_status() == 0
     o1, o0 = outs[True].cpu().double(), outs[False].cpu().double()
     assert not torch.isnan(o1).any()
@@ -238,108 +247,6 @@ def test_k32_conv_flags_outputs_beyond_the_split_fp16_range(eng_split):
     assert eng.k32_capable(pk, 1, out, None, None, None)
     assert eng.read_status() & 1
     assert eng.read_status() == 0
-
-
-S16_CASES = [
-    # cin segments, cout, H, W, N, ps, in_slope, out_slope, res ("f32"/"s16"/None), gate, res2, twin act ("none" = no twin), f32 out
-    ((64,), 64, 40, 72, 1, False, None, 0.01, "f32", False, None, "none", True),      # partial tiles in both directions
-    ((64,), 64, 33, 95, 2, False, 0.01, None, "f32", False, "f32", 0.01, True),       # ResBlock conv2: res + res2, twin for the next block
-    ((64,), 64, 32, 64, 1, False, 0.1, 0.1, None, False, None, None, False),           # ResBlock conv1: s16-only output
-    ((32, 64), 64, 48, 64, 1, False, None, None, None, False, None, None, True),       # two segments (recon first_conv)
-    ((64, 64), 64, 20, 40, 1, False, None, 0.01, "s16", False, None, None, False),     # residual read from an s16 tensor
-    ((128,), 128, 34, 66, 1, False, None, 0.0, "f32", False, None, 0.0, True),         # two output-channel blocks
-    ((128,), 256, 18, 34, 2, True, None, 0.01, None, False, None, None, True),         # PixelShuffle
-    ((64,), 32, 16, 32, 1, False, None, 0.01, None, False, None, None, False),         # one 32-channel tile
-    ((32,), 32, 50, 50, 1, False, None, None, "f32", True, None, "none", True),        # gated residual
-    ((64,), 96, 17, 33, 1, False, None, "clamp01", None, False, None, None, True),     # Cout padded to 128, clamp
-    ((16, 16, 16), 48, 16, 16, 1, False, 0.2, None, None, False, "s16", 0.2, True),    # three segments, s16 res2
-]
-
-
-@pytest.mark.parametrize("case", S16_CASES, ids=[f"s{i}" for i in range(len(S16_CASES))])
-def test_s16_conv_is_bit_identical_to_fp16x3_kernel(eng_split, case):
-    """dcvc_conv2d_s16 (pre-split activations, LDS-DMA, persistent tiles) against dcvc_conv2d in
-    DCVC_PREC_FP16X3 mode on the same numbers: the operand split, the three products and their order
-    are the same, so the fp32 results must be IDENTICAL, not close -- and therefore inherit the fp64
-    error bound of test_split_fp16_conv_matches_fp64.  The s16 outputs are checked by unpacking them
-    (hi + lo is exact in fp32) against split(act(result)) computed on the host."""
-    segs, cout, H, W, N, ps, in_slope, out_slope, res_fmt, use_gate, res2_fmt, twin_act, want_f32 = case
-    eng = eng_split
-    assert eng.s16_enabled()
-    g = torch.Generator().manual_seed(S16_CASES.index(case) + 100)
-    cin = sum(segs)
-    mag = torch.tensor([1e-3, 1.0, 20.0])[torch.randint(0, 3, (N, cin, 1, 1), generator=g)]
-    x = torch.randn(N, cin, H, W, generator=g) * mag
-    w = torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(cin * 9)
-    b = torch.randn(cout, generator=g) * 0.1
-    pk = eng.pack(("s16t", case), torch.nn.Parameter(w.cuda()), torch.nn.Parameter(b.cuda()), segs, ps)
-    m = 2 if ps else 1
-    cfin = cout // 4 if ps else cout
-
-    def quant(t):  # what an s16 tensor can hold: hi + lo of the split
-        s = (t * 8).clamp(-65504, 65504)
-        hi = s.half().float()
-        return (hi + (s - hi).half().float()) / 8
-
-    fviews, sviews, c0 = [], [], 0
-    for i, c in enumerate(segs):
-        fv = to_view(eng, f"s16t/in{i}", x[:, c0 : c0 + c], cs=(c + 15) // 16 * 16)
-        sviews.append(eng.s16_pack(fv, act=in_slope))
-        fviews.append(fv)
-        c0 += c
-    res = res2 = gate = None
-    rshape = (N, cfin, H * m, W * m)
-    if res_fmt:
-        r = torch.randn(rshape, generator=g)
-        res = to_view(eng, "s16t/res", quant(r) if res_fmt == "s16" else r, cs=(cfin + 15) // 16 * 16)
-    if res2_fmt:
-        r2 = torch.randn(rshape, generator=g)
-        res2 = to_view(eng, "s16t/res2", quant(r2) if res2_fmt == "s16" else r2, cs=(cfin + 15) // 16 * 16)
-    if use_gate:
-        gate = torch.rand(N, cfin, generator=g).cuda()
-    # reference: the fp32-activation kernel of the same arithmetic
-    want = eng.buf("s16t/want", N, H * m, W * m, cfin)
-    eng._conv_f32(pk, fviews, want, 1, in_slope, out_slope, res, gate, res2)
-    want_t = eng.to_nchw(want).cpu()
-    # fast path: inputs are the s16 twins only
-    srcs = [View_s16_only(v) for v in sviews]
-    res_v = eng.s16_pack(res, None) if res_fmt == "s16" else res
-    res2_v = eng.s16_pack(res2, None) if res2_fmt == "s16" else res2
-    if want_f32:
-        out = eng.buf("s16t/out", N, H * m, W * m, cfin, twin=False if twin_act == "none" else twin_act)
-        out.base.fill_(float("nan"))
-    else:
-        out = eng.buf("s16t/out16", N, H * m, W * m, cfin, fmt="s16", act=None)
-    calls = eng.calls
-    eng.conv(pk, srcs, out, in_slope=in_slope, out_slope=out_slope, res=res_v, gate=gate, res2=res2_v)
-    assert eng.calls == calls + 1  # one launch: no conversion pass, no fallback
-    if want_f32:
-        assert torch.equal(eng.to_nchw(out).cpu(), want_t)
-    o16 = out if out.fmt == "s16" else out.twin
-    if o16 is not None:
-        back = eng.s16_unpack(o16, eng.buf("s16t/back", N, H * m, W * m, cfin))
-        a16 = want_t if o16.act is None else F.leaky_relu(want_t, o16.act)
-        assert torch.equal(eng.to_nchw(back).cpu(), quant(a16))
-    eng.check_status()
-
-
-def View_s16_only(v):
-    """Drop every fp32 handle: the kernel under test must not be able to fall back."""
-    from vcm_ts_amd.engine import View
-
-    return View(v.base, v.C, 0, geom=(v.N, v.H, v.W, v.cs, v.ptr), fmt="s16", act=v.act)
-
-
-def test_s16_saturation_is_reported(eng_split):
-    """|activation| > 8188 cannot be stored split: the value is clamped AND the status word says so."""
-    eng = eng_split
-    x = torch.zeros(1, 16, 16, 32)
-    x[0, 3, 5, 7] = 9000.0
-    v = to_view(eng, "sat/in", x, cs=16)
-    eng.s16_pack(v)
-    with pytest.raises(Exception, match="range"):
-        eng.check_status()
-    eng.check_status()  # cleared
 
 
 @pytest.mark.parametrize("case", CONV_CASES, ids=[f"c{i}" for i in range(len(CONV_CASES))])

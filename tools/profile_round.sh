@@ -1,9 +1,9 @@
 #!/bin/bash
 # Round profiles on the GPU box (run through gpurun): kernel-trace stats and the two PMC traffic passes of the
-# bench command, plus stats / traffic of the pre-split kernel through the probe.  Writes under gpurun_out/prof_rNN.
+# bench command, plus stats / traffic of both 3x3 kernels through the probe.  Writes under gpurun_out/prof_rNN.
 # usage: tools/profile_round.sh r02
 set -u
-R=${1:-r02}
+R=${1:-r03}
 OUT=gpurun_out/prof_$R
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
@@ -12,19 +12,19 @@ rocprofv3 --kernel-trace --stats -d $OUT -o stats1 -- python3 $B --gop-streams 1
 rocprofv3 --kernel-trace --stats -d $OUT -o stats2 -- python3 $B > $OUT/stats2.log 2>&1 && echo stats2 done
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT -o fetch -- python3 $B --gop-streams 1 > $OUT/fetch.log 2>&1 && echo fetch done
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT -o write -- python3 $B --gop-streams 1 > $OUT/write.log 2>&1 && echo write done
-rocprofv3 --kernel-trace --stats -d $OUT -o s16stats -- python3 tools/conv_probe.py 64 64 3 fp16x3 > $OUT/s16stats.log 2>&1 && echo s16stats done
-rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT -o s16fetch -- python3 tools/conv_probe.py 64 64 3 fp16x3 > $OUT/s16fetch.log 2>&1 && echo s16fetch done
-rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT -o s16write -- python3 tools/conv_probe.py 64 64 3 fp16x3 > $OUT/s16write.log 2>&1 && echo s16write done
+rocprofv3 --kernel-trace --stats -d $OUT -o probestats -- python3 tools/conv_probe.py 64 64 3 fp16x3 > $OUT/probestats.log 2>&1 && echo probestats done
+rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT -o probefetch -- python3 tools/conv_probe.py 64 64 3 fp16x3 > $OUT/probefetch.log 2>&1 && echo probefetch done
+rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT -o probewrite -- python3 tools/conv_probe.py 64 64 3 fp16x3 > $OUT/probewrite.log 2>&1 && echo probewrite done
 
 # summaries (small text / JSON) -- the databases are too big to travel back
 python3 tools/rocprof_summary.py $OUT/stats1_results.db > $OUT/${R}_bench_gop_streams_1_kernel_stats.txt
 python3 tools/rocprof_summary.py $OUT/stats2_results.db > $OUT/${R}_bench_gop_streams_2_kernel_stats.txt
 python3 tools/rocprof_pmc.py $OUT/fetch_results.db FETCH_SIZE > $OUT/${R}_fp16x3_pmc_fetch_size.txt
 python3 tools/rocprof_pmc.py $OUT/write_results.db WRITE_SIZE > $OUT/${R}_fp16x3_pmc_write_size.txt
-python3 tools/rocprof_traffic.py $OUT/fetch_results.db $OUT/write_results.db 'conv_mfma<3, 1, 2, 2, true>' fp16x3 1080 1920 > $OUT/traffic_bench.json
+python3 tools/rocprof_traffic.py $OUT/fetch_results.db $OUT/write_results.db 'conv_k32<3, 4>' fp16x3 1080 1920 > $OUT/traffic_bench.json
 cp profiles/pmc_traffic_fp16x3.json $OUT/pmc_traffic_fp16x3.json
-python3 tools/rocprof_summary.py $OUT/s16stats_results.db > $OUT/${R}_conv_probe_64_kernel_stats.txt
-python3 tools/rocprof_pmc.py $OUT/s16fetch_results.db FETCH_SIZE > $OUT/${R}_conv_probe_64_pmc_fetch_size.txt
-python3 tools/rocprof_pmc.py $OUT/s16write_results.db WRITE_SIZE > $OUT/${R}_conv_probe_64_pmc_write_size.txt
+python3 tools/rocprof_summary.py $OUT/probestats_results.db > $OUT/${R}_conv_probe_64_kernel_stats.txt
+python3 tools/rocprof_pmc.py $OUT/probefetch_results.db FETCH_SIZE > $OUT/${R}_conv_probe_64_pmc_fetch_size.txt
+python3 tools/rocprof_pmc.py $OUT/probewrite_results.db WRITE_SIZE > $OUT/${R}_conv_probe_64_pmc_write_size.txt
 rm -f $OUT/*.db
 ls -la $OUT

@@ -24,19 +24,12 @@ def _r4(c):
 
 
 class View:
-    """C channels starting at channel `coff` of an (N, H, W, cs) buffer.
+    """C channels starting at channel `coff` of an fp32 (N, H, W, cs) buffer."""
 
-    fmt "f32": fp32 NHWC (the default everywhere).  fmt "s16": the split-fp16 layout of
-    include/dcvc_hip.h ("pre-split activations"): same geometry and byte strides, every 16-channel
-    chunk of a pixel stored as [16 x fp16 hi | 16 x fp16 lo]; `act` is the LeakyReLU slope the producer
-    applied on top of the logical tensor (None: the tensor itself).  An fp32 view may carry an s16
-    `twin` of the same logical tensor, written by the same producer launch."""
+    __slots__ = ("base", "N", "H", "W", "C", "cs", "coff", "ptr")
 
-    __slots__ = ("base", "N", "H", "W", "C", "cs", "coff", "ptr", "fmt", "act", "twin")
-
-    def __init__(self, base: torch.Tensor, C_: int, coff: int = 0, geom=None, fmt="f32", act=None):
+    def __init__(self, base: torch.Tensor, C_: int, coff: int = 0, geom=None):
         self.base = base
-        self.fmt, self.act, self.twin = fmt, act, None
         if geom is None:
             assert base.dim() == 4 and base.dtype == torch.float32 and base.is_contiguous()
             self.N, self.H, self.W, self.cs = base.shape
@@ -61,25 +54,12 @@ class View:
         return None
 
     def slice(self, c0: int, c: int) -> "View":
-        # an s16 buffer is planar in 16-channel chunks: a slice is a run of planes
-        assert self.fmt == "f32" or (c0 % 16 == 0 and c % 16 == 0)
-        off = 4 * c0 if self.fmt == "f32" else 4 * c0 * self.H * self.W
-        v = View(self.base, c, 0, geom=(self.N, self.H, self.W, self.cs, self.ptr + off), fmt=self.fmt, act=self.act)
+        v = View(self.base, c, 0, geom=(self.N, self.H, self.W, self.cs, self.ptr + 4 * c0))
         v.coff = self.coff + c0
-        if self.twin is not None and c0 % 16 == 0 and c % 16 == 0:
-            v.twin = self.twin.slice(c0, c)
         return v
-
-    def s16(self, act=None):
-        """The s16 form of this tensor with input activation `act` applied, if some producer wrote it."""
-        for v in (self, self.twin):
-            if v is not None and v.fmt == "s16" and v.act == act:
-                return v
-        return None
 
     def nchw(self) -> torch.Tensor:
         """Zero-copy logical (N, C, H, W) tensor over this view (channels-last strides)."""
-        assert self.fmt == "f32"
         if self.base.dim() == 4 and tuple(self.base.shape) == (self.N, self.H, self.W, self.cs):
             return self.base[..., self.coff : self.coff + self.C].permute(0, 3, 1, 2)
         return self.base[:, self.coff : self.coff + self.C]  # alias of a caller's logical-NCHW tensor
@@ -94,7 +74,7 @@ class View:
 
 class PackedConv:
     __slots__ = ("w", "b", "ks", "Cout", "Cout_pad", "seg_C", "ps", "version", "precision", "weight", "bias",
-                 "cin_slice", "key", "s16", "small", "k32", "host", "job")
+                 "cin_slice", "key", "small", "k32", "host", "job")
 
 
 class Engine:
@@ -119,11 +99,11 @@ class Engine:
         self.tape = None     # grad.Tape while a training-mode forward is being recorded
         self._edges = {}     # distribution -> device (256,) fp32 bin edges of build_indexes
         self._status = None  # device status word of the split-fp16 kernels (saturation flag)
-        self.use_s16 = os.environ.get("DCVC_S16", "1") != "0"
         self.use_small = os.environ.get("DCVC_SMALL", "1") != "0"   # dcvc_conv2d_small for <= 16 output channels
         # dcvc_conv2d_k32 (16x16x32 MFMA, 32-channel chunks) for the stride-1 3x3 / 1x1 layers it covers; DCVC_K32=0
         # keeps them on dcvc_conv2d (developer A/B switch: an encoder and its decoder must use the same setting)
         self.use_k32 = os.environ.get("DCVC_K32", "1") != "0"
+        self.k32_sizes = tuple(int(k) for k in os.environ.get("DCVC_K32_SIZES", "3").split(","))  # kernel sizes it takes (1x1 layers are HBM-bound: conv_mfma's full-line stores are 10-15 % faster there)
         # fp16x3 mode clamps |activation| > 8188 on load; with range_check on, every convolution launch also
         # flags outputs beyond that magnitude in the status word (check_status() raises).  Off by default: it
         # costs VALU work in the epilogue; bench.py and the tests turn it on for a checked pass.
@@ -143,28 +123,15 @@ class Engine:
         that live as long as its tape, because backward reads every intermediate."""
         return self.bufs if (self.tape is None or scratch) else self.tape.arena
 
-    def buf(self, name, N, H, W, C_, cs=None, zero=False, fmt="f32", act=None, twin=False) -> View:
-        """fmt "s16": an s16-only tensor (act: activation its producer applies).  twin: False, or the
-        activation (None = raw, or a slope) of an s16 twin allocated next to the fp32 buffer."""
-        if fmt == "s16" or twin is not False:
-            cs = cs or (C_ + 15) // 16 * 16
-            assert cs % 16 == 0 and C_ % 16 == 0, (name, C_, cs)
+    def buf(self, name, N, H, W, C_, cs=None, zero=False) -> View:
         cs = cs or _r4(C_)
-        key = (name, N, H, W, cs) if fmt == "f32" else (name, N, H, W, cs, "s16")
+        key = (name, N, H, W, cs)
         store = self._store()
         t = store.get(key)
         if t is None:
             t = (torch.zeros if zero else torch.empty)((N, H, W, cs), dtype=torch.float32, device=self.device)
             store[key] = t
-        v = View(t, C_, fmt=fmt, act=act if fmt == "s16" else None)
-        if twin is not False:
-            v.twin = self.buf(name + "#s16", N, H, W, C_, cs=cs, fmt="s16", act=twin)
-        return v
-
-    def s16_enabled(self) -> bool:
-        """Pre-split activations are an inference-time form of the fp16x3 arithmetic (the gradient
-        kernels read fp32 activations)."""
-        return self.precision == "fp16x3" and self.tape is None and self.use_s16
+        return View(t, C_)
 
     def status_word(self) -> torch.Tensor:
         if self._status is None:
@@ -185,28 +152,6 @@ class Engine:
         v = self.read_status()
         if v:
             raise lib.KernelError(f"split-fp16 activation range exceeded (status {v}): |x| > 8188; use precision='fp32'")
-
-    def s16_pack(self, src: View, act=None) -> View:
-        """fp32 view -> its s16 twin by a conversion pass (for tensors no fast-path convolution produced)."""
-        if src.twin is None or src.twin.act != act:
-            src.twin = View(self._twin_tensor(src), src.C, fmt="s16", act=act)
-        t = src.twin
-        self.s16_pack_into(src, t)
-        return t
-
-    def _twin_tensor(self, src: View) -> torch.Tensor:
-        cs = (src.C + 15) // 16 * 16
-        key = ("#twin", src.ptr, src.N, src.H, src.W, cs)
-        t = self.bufs.get(key)
-        if t is None:
-            t = torch.zeros((src.N, src.H, src.W, cs), dtype=torch.float32, device=self.device)
-            self.bufs[key] = t
-        return t
-
-    def s16_unpack(self, src: View, out: View) -> View:
-        lib.check(self.L.dcvc_s16_unpack(src.ptr, src.cs, out.ptr, out.cs, src.N, src.HW, src.C, self.stream()), "s16_unpack")
-        self.calls += 1
-        return out
 
     def ibuf(self, name, n) -> torch.Tensor:
         key = (name, n, "i32")
@@ -396,32 +341,6 @@ class Engine:
         self.packs[key] = pk
         return pk
 
-    def pack_s16(self, pk: PackedConv) -> PackedConv:
-        """The same layer packed for dcvc_conv2d_s16 (cached beside the fp16x3 packing)."""
-        q = getattr(pk, "s16", None)  # (slot is unset until the first call)
-        if q is not None and q.version == pk.version:
-            return q
-        w = pk.weight.detach().float().cpu()
-        if pk.cin_slice is not None:
-            w = w[:, pk.cin_slice[0] : pk.cin_slice[1]]
-        w = w.contiguous().numpy()
-        b = None if pk.bias is None else pk.bias.detach().float().cpu().contiguous().numpy()
-        segs = (C.c_int32 * len(pk.seg_C))(*pk.seg_C)
-        cpad = C.c_int32()
-        n = self.L.dcvc_conv_s16_pack_bytes(pk.Cout, pk.ks, len(pk.seg_C), segs, C.byref(cpad))
-        if n < 0:
-            raise lib.KernelError(f"conv_s16_pack_bytes({pk.key})")
-        wp = np.empty(n // 4, np.float32)
-        bp = np.empty(cpad.value, np.float32)
-        lib.check(self.L.dcvc_conv_s16_pack_weights(w.ctypes.data, None if b is None else b.ctypes.data, pk.Cout, pk.ks,
-                                                    len(pk.seg_C), segs, int(pk.ps), wp.ctypes.data, bp.ctypes.data),
-                  f"conv_s16_pack_weights({pk.key}) [status -3: a |weight| >= 1023.5 does not fit split fp16, use precision='fp32']")
-        q = PackedConv()
-        q.w, q.b = torch.from_numpy(wp).to(self.device), torch.from_numpy(bp).to(self.device)
-        q.ks, q.Cout, q.Cout_pad, q.seg_C, q.ps, q.version, q.key = pk.ks, pk.Cout, cpad.value, pk.seg_C, pk.ps, pk.version, pk.key
-        pk.s16 = q
-        return q
-
     def pack_small(self, pk: PackedConv) -> PackedConv:
         """The same layer packed for dcvc_conv2d_small (<= 16 output channels), cached beside the other packing."""
         q = getattr(pk, "small", None)
@@ -474,13 +393,13 @@ class Engine:
         return q
 
     def k32_capable(self, pk: PackedConv, stride, out: View, res, res2, gate) -> bool:
-        """Layers dcvc_conv2d_k32 covers: fp16x3, 3x3, stride 1, every input segment a multiple of 32 channels,
+        """Layers dcvc_conv2d_k32 covers: fp16x3, 3x3 or 1x1, stride 1, every input segment a multiple of 32 channels,
         16-byte-addressable epilogue (4-channel groups of out / residuals)."""
         if not (self.precision == "fp16x3" and self.tape is None and self.use_k32 and getattr(pk, "host", False)):
             return False
         cfin = pk.Cout // 4 if pk.ps else pk.Cout
         al = lambda v: v is None or (v.ptr % 16 == 0 and v.cs % 4 == 0)
-        return (pk.ks == 3 and stride == 1 and all(c % 32 == 0 for c in pk.seg_C) and cfin % 4 == 0
+        return (pk.ks in self.k32_sizes and stride == 1 and all(c % 32 == 0 for c in pk.seg_C) and cfin % 4 == 0
                 and al(out) and al(res) and al(res2) and (gate is None or gate.data_ptr() % 16 == 0))
 
     def small_capable(self, pk: PackedConv, stride, gate, res2, chan_partial) -> bool:
@@ -489,69 +408,12 @@ class Engine:
                 and pk.Cout <= 16 and pk.ks in (3, 7)
                 and stride == 1 and not pk.ps and gate is None and res2 is None and chan_partial is None)
 
-    def s16_capable(self, pk: PackedConv, stride=1) -> bool:
-        """Layer geometry dcvc_conv2d_s16 covers (3x3, stride 1, 16-channel granularity)."""
-        cfin = pk.Cout // 4 if pk.ps else pk.Cout
-        return (self.s16_enabled() and getattr(pk, "host", False) and pk.ks == 3 and stride == 1 and pk.Cout % 16 == 0
-                and cfin % 16 == 0
-                and all(c % 16 == 0 for c in pk.seg_C))
-
     def conv(self, pk: PackedConv, srcs, out: View, stride=1, in_slope=None, out_slope=None, res: View = None,
              gate: torch.Tensor = None, res2: View = None, chan_partial: torch.Tensor = None):
-        """out: an fp32 view (its `twin`, if any, is written by the same launch with the twin's
-        activation) or an s16-only view.  chan_partial: buffer from chan_partial_buf() that receives the
-        per-workgroup channel sums of the output (fused SE squeeze)."""
-        want16 = out if out.fmt == "s16" else out.twin
-        if chan_partial is None and self.s16_capable(pk, stride):
-            s16_srcs = [s.s16(in_slope) for s in srcs]
-            if all(v is not None for v in s16_srcs):
-                return self._conv_s16(pk, srcs, s16_srcs, out, out_slope, res, gate, res2)
-        assert out.fmt == "f32" and all(s.fmt == "f32" for s in srcs), ("s16-only tensor reached the fp32 kernel", pk.key)
-        self._conv_f32(pk, srcs, out, stride, in_slope, out_slope, res, gate, res2, chan_partial)
-        if want16 is not None and self.s16_enabled():
-            self.s16_pack_into(out, want16)
-        return out
-
-    def s16_pack_into(self, src: View, t: View):
-        lib.check(self.L.dcvc_s16_pack(src.ptr, src.cs, t.ptr, t.cs, src.N, src.HW, src.C, int(t.act is not None),
-                                       float(t.act or 0.0), self.status_word().data_ptr(), self.stream()), "s16_pack")
-        self.calls += 1
-
-    def _conv_s16(self, pk, srcs, s16_srcs, out: View, out_slope, res, gate, res2):
-        q = self.pack_s16(pk)
-        a = lib.ConvS16Args()
-        s0 = srcs[0]
-        for i, (s, c) in enumerate(zip(s16_srcs, pk.seg_C)):
-            assert s.C == c and (s.N, s.H, s.W) == (s0.N, s0.H, s0.W), (s, c)
-            a.seg[i].ptr, a.seg[i].C, a.seg[i].cs = s.ptr, s.C, s.cs
-        a.nseg, a.N, a.H, a.W = len(srcs), s0.N, s0.H, s0.W
-        a.wpack, a.bpack, a.ks, a.Cout, a.Cout_pad = q.w.data_ptr(), q.b.data_ptr(), q.ks, q.Cout, q.Cout_pad
-        m = 2 if pk.ps else 1
-        cfin = pk.Cout // 4 if pk.ps else pk.Cout
-        assert (out.N, out.H, out.W, out.C) == (s0.N, s0.H * m, s0.W * m, cfin), (out, cfin)
-        a.out_act, a.out_slope = (0, 0.0) if out_slope is None else ((2, 0.0) if out_slope == "clamp01" else (1, out_slope))
-        o16 = out if out.fmt == "s16" else out.twin
-        if out.fmt == "f32":
-            a.out, a.out_cs = out.ptr, out.cs
-        if o16 is not None:
-            a.out16, a.out16_cs = o16.ptr, o16.cs
-            a.out16_act, a.out16_slope = (0, 0.0) if o16.act is None else (1, o16.act)
-        a.pixel_shuffle = int(pk.ps)
-        fmt = {"f32": 0, "s16": 1}
-        for nm, r in (("res", res), ("res2", res2)):
-            if r is not None:
-                assert (r.N, r.H, r.W, r.C) == (out.N, out.H, out.W, out.C)
-                assert r.fmt == "f32" or r.act is None
-                setattr(a, nm, r.ptr)
-                setattr(a, nm + "_cs", r.cs)
-                setattr(a, nm + "_fmt", fmt[r.fmt])
-        if gate is not None:
-            a.res_gate = gate.data_ptr()
-        a.status = self.status_word().data_ptr()
-        self._launch_conv(lambda: lib.check(self.L.dcvc_conv2d_s16(C.byref(a), self.stream()), "conv2d_s16"), pk, s0, s0.H, s0.W,
-                          1, res, res2, "s16")
-        self.calls += 1
-        return out
+        """chan_partial: buffer from chan_partial_buf() that receives the per-workgroup channel sums of the output
+        (fused SE squeeze).  Which kernel serves the layer (conv_mfma / conv_k32 / conv_small) is decided in
+        _conv_f32 from the layer's geometry alone, so an encoder and its decoder always agree."""
+        return self._conv_f32(pk, srcs, out, stride, in_slope, out_slope, res, gate, res2, chan_partial)
 
     def _launch_conv(self, launch, pk, s0, Ho, Wo, stride, res, res2, tag="", note=""):
         if self.profile is None:

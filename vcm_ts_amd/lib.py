@@ -74,18 +74,6 @@ class ConvArgs(C.Structure):
     ]
 
 
-class ConvS16Args(C.Structure):
-    _fields_ = [
-        ("seg", Seg * 3), ("nseg", C.c_int32), ("N", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
-        ("wpack", C.c_void_p), ("bpack", C.c_void_p), ("ks", C.c_int32), ("Cout", C.c_int32), ("Cout_pad", C.c_int32),
-        ("out", C.c_void_p), ("out_cs", C.c_int32), ("out_act", C.c_int32), ("out_slope", C.c_float),
-        ("out16", C.c_void_p), ("out16_cs", C.c_int32), ("out16_act", C.c_int32), ("out16_slope", C.c_float),
-        ("pixel_shuffle", C.c_int32), ("res", C.c_void_p), ("res_cs", C.c_int32), ("res_fmt", C.c_int32),
-        ("res_gate", C.c_void_p), ("res2", C.c_void_p), ("res2_cs", C.c_int32), ("res2_fmt", C.c_int32),
-        ("status", C.c_void_p),
-    ]
-
-
 class DualPriorArgs(C.Structure):
     _fields_ = [
         ("y", C.c_void_p), ("y_cs", C.c_int32), ("fusion", C.c_void_p), ("fusion_cs", C.c_int32),
@@ -151,10 +139,6 @@ _SIGS = {
     "dcvc_conv_small_pack_weights": [vp, vp, i32, i32, i32, vp, vp, vp],
     "dcvc_conv2d_k32": [C.POINTER(ConvArgs), vp],
     "dcvc_conv_k32_pack_weights": [vp, vp, i32, i32, i32, vp, i32, vp, vp],
-    "dcvc_conv2d_s16": [C.POINTER(ConvS16Args), vp],
-    "dcvc_conv_s16_pack_weights": [vp, vp, i32, i32, i32, vp, i32, vp, vp],
-    "dcvc_s16_pack": [vp, i32, vp, i32, i32, i64, i32, i32, f32, vp, vp],
-    "dcvc_s16_unpack": [vp, i32, vp, i32, i32, i64, i32, vp],
     "dcvc_warp": [vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, vp],
     "dcvc_up2": [vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, f32, vp],
     "dcvc_down2": [vp, i32, vp, i32, i32, i32, i32, i32, f32, i32, vp],
@@ -205,7 +189,7 @@ _SIGS = {
     "dcvc_drans_build_lut": [vp, i32, i32, vp, vp],
 }
 
-HIP_SYMBOLS = sorted(list(_SIGS) + ["dcvc_cdf_table_cols", "dcvc_conv_pack_size", "dcvc_conv_small_pack_bytes", "dcvc_conv_s16_pack_bytes", "dcvc_conv_k32_pack_bytes", "dcvc_conv_chan_partial_parts", "dcvc_hip_version", "dcvc_conv_wgrad_scratch_min",
+HIP_SYMBOLS = sorted(list(_SIGS) + ["dcvc_cdf_table_cols", "dcvc_conv_pack_size", "dcvc_conv_small_pack_bytes", "dcvc_conv_k32_pack_bytes", "dcvc_conv_chan_partial_parts", "dcvc_hip_version", "dcvc_conv_wgrad_scratch_min",
                                     "dcvc_drans_default_lanes", "dcvc_drans_scratch_words"])
 RANS_SYMBOLS = [
     "dcvc_rans_encoder_create", "dcvc_rans_encoder_destroy", "dcvc_rans_encoder_reset",
@@ -232,8 +216,6 @@ def hip():
         L.dcvc_conv_chan_partial_parts.restype = i32
         L.dcvc_conv_small_pack_bytes.argtypes = [i32, i32, i32, vp]
         L.dcvc_conv_small_pack_bytes.restype = i64
-        L.dcvc_conv_s16_pack_bytes.argtypes = [i32, i32, i32, vp, C.POINTER(i32)]
-        L.dcvc_conv_s16_pack_bytes.restype = i64
         L.dcvc_conv_k32_pack_bytes.argtypes = [i32, i32, i32, vp, C.POINTER(i32)]
         L.dcvc_conv_k32_pack_bytes.restype = i64
         L.dcvc_hip_version.restype = C.c_char_p
