@@ -57,6 +57,16 @@ def host_cores():
     return max(1, min(n, 16))
 
 
+def host_cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.lower().startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def kernel_source_hash():
     """sha256 (16 hex) over the convolution kernel sources and the build flags: a committed PMC figure is only
     quoted for the kernels it was measured on."""
@@ -257,7 +267,7 @@ def train_workload(args, dev, rank, world):
                                         w["mv_y_q_scale"], w["y_q_scale"], noise=noise)
         (o["bpp"] + torch.tensor([85.0, 170.0, 380.0, 840.0]) * o["mse"]).mean().backward()
         sec = time.time() - t0
-        out["cpu_baseline"] = {"value": round(batch / sec, 3), "unit": "pictures/s", "cores": cores, "kind": "port",
+        out["cpu_baseline"] = {"value": round(batch / sec, 3), "unit": "pictures/s", "cores": cores, "cpu_model": host_cpu_model(), "kind": "port",
                                "sample": f"1 step (forward + torch.autograd backward, no optimiser) of the oracle on the same batch: {sec:.1f} s"}
     return out
 
@@ -395,20 +405,23 @@ def main():
             bits_gop0[0] = res[0][1]
         return b
 
-    dt, bits = timed_region(work, dev)
+    dt, bits, dt_local = timed_region(work, dev, with_local=True)
     bits = bits / K  # per GOP
     frames_total = K * args.gop * args.steps * world
     fps = frames_total / dt
-    # the same GOP alone on the GPU (one stream), untimed for `value`: gives the one-stream rate, the
-    # per-picture PSNR of this mode's reconstructions and a range-checked pass (every convolution output
-    # tested against the magnitude the split-fp16 operands can hold)
+    # the same GOP alone on the GPU (one stream), untimed for `value`: first plainly (the one-stream rate), then once
+    # more as a CHECKED pass: per-picture PSNR of this mode's reconstructions and every convolution output tested
+    # against the magnitude the split-fp16 operands can hold (conv_k32's guard is always on; this adds the others)
     eng_i, eng_p = i_net.engine(), p_net.engine()
+    dt1, bits1 = timed_region(lambda: enc.encode_gop(seq, q_i, q_mv, q_y)[1], dev)
+    one_stream = round(args.gop / dt1, 3)
+    saturation = eng_i.read_status() | eng_p.read_status()  # what the always-on guard saw during the timed steps
     eng_i.range_check = eng_p.range_check = True
     quality = GopQuality(seq, args.height, args.width)
-    dt1, bits1 = timed_region(lambda: enc.encode_gop(seq, q_i, q_mv, q_y, on_recon=quality)[1], dev)
-    saturation = eng_i.read_status() | eng_p.read_status()
+    bits1_checked = enc.encode_gop(seq, q_i, q_mv, q_y, on_recon=quality)[1]
+    assert bits1_checked == bits1, "the checked pass codes the same bytes"
+    saturation |= eng_i.read_status() | eng_p.read_status()
     eng_i.range_check = eng_p.range_check = False
-    one_stream = round(args.gop / dt1, 3)
     psnr_fast = quality.psnr()
 
     # ---- roofline of the dominant kernel, measured live with HIP events on the launch stream
@@ -478,6 +491,7 @@ def main():
                    "parallelism": f"gop-sharded x{world} GPUs x{K} concurrent GOP streams per GPU",
                    "gops_per_step_per_gpu": K, "frames_per_step_per_gpu": K * args.gop,
                    "one_gop_stream_frames_per_s": one_stream,
+                   "device": torch.cuda.get_device_name(dev), "device_uuid": str(getattr(torch.cuda.get_device_properties(dev), "uuid", "")),
                    "bits_per_gop": int(bits), "bpp": round(bits / (args.gop * args.height * args.width), 4),
                    "psnr_db_gop_mean": round(float(psnr_fast.mean()), 4),
                    "psnr_note": "random-init weights: PSNR is a parity quantity here, not codec quality",
@@ -542,7 +556,8 @@ def main():
         sec_1 = cpu_baseline(sh, sw, 1) * (int(ph) * int(pw)) / (sh * sw)
         t_enc, t_dec, nbytes = cpu_rans_baseline(planes)
         out["cpu_baseline"] = {
-            "value": round(1.0 / (sec_all + t_enc), 5), "unit": "frames/s", "cores": cores, "kind": "port",
+            "value": round(1.0 / (sec_all + t_enc), 5), "unit": "frames/s", "cores": cores, "cpu_model": host_cpu_model(),
+            "kind": "port",
             "sample": f"1 P picture {ph}x{pw}: networks of DMC.compress through oracle/dcvc_ref.py (torch-CPU fp32, {cores} threads) "
                       f"{sec_all:.1f} s + rANS encode of its 6 symbol planes through oracle/rans_ref.c (1 thread) {t_enc * 1e3:.0f} ms",
             "breakdown": {"nets_s_per_frame_all_cores": round(sec_all, 2), "nets_s_per_frame_1_thread": round(sec_1, 1),
@@ -552,7 +567,19 @@ def main():
                           "end_to_end_fps_all_cores": round(1.0 / (sec_all + t_enc), 5),
                           "end_to_end_fps_1_thread": round(1.0 / (sec_1 + t_enc), 6)}}
     if grouped:
+        # self-verification of a multi-GPU run: how many ranks the collective backend really joined (an all-reduce of
+        # ones over the process group: RCCL when the backend is nccl) and what each rank delivered by its own clock
+        on_gpu = dist.get_backend() == "nccl"
+        one = torch.ones(1, dtype=torch.float64, device=dev if on_gpu else "cpu")
+        dist.all_reduce(one)
+        mine = torch.tensor([K * args.gop * args.steps / dt_local], dtype=torch.float64, device=dev if on_gpu else "cpu")
+        every = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+        dist.all_gather(every, mine)
         out["config"]["dist_backend"] = args.dist_backend
+        out["config"]["collective_ranks"] = int(round(float(one.item())))
+        if on_gpu:
+            out["config"]["rccl_ranks"] = int(round(float(one.item())))
+        out["config"]["per_rank_frames_per_s"] = [round(float(t.item()), 3) for t in every]
     if rank == 0:
         print(json.dumps(out))
     if grouped:

@@ -104,7 +104,15 @@ typedef struct {
                              workgroup writes the per-channel sums of the outputs it stored, so that SELayer's global
                              average pool (video_net.py:149-162) costs no second pass over the tensor; finish with
                              dcvc_channel_mean_finish.  Not with pixel_shuffle; needs the 16-byte aligned epilogue. */
+    int32_t tile_row0;    /* with tile_rows > 0: compute only the output rows of tile rows [tile_row0, tile_row0 +    */
+    int32_t tile_rows;    /* tile_rows) (a tile row = dcvc_conv_tile_rows() output rows; pixels outside the band are   */
+                          /* left untouched, inputs above / below it are read as usual).  0, 0: the whole picture.     */
+                          /* A host that runs consecutive layers band by band keeps a layer's output in the 256 MB    */
+                          /* Infinity Cache until its consumer reads it (vcm_ts_amd/engine.py: banded launches).       */
 } dcvc_conv_args;
+
+/* output rows per tile row of dcvc_conv2d / dcvc_conv2d_k32 for this kernel size and stride (the band granularity) */
+int32_t dcvc_conv_tile_rows(int32_t ks, int32_t stride);
 
 /* number of partial rows per image dcvc_conv2d writes to chan_partial for this output size */
 int32_t dcvc_conv_chan_partial_parts(int32_t ks, int32_t stride, int32_t Hout, int32_t Wout);

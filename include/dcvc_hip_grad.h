@@ -129,8 +129,10 @@ int dcvc_add_planes(const float *a, int32_t a_cs, const float *b, int32_t b_cs, 
                     int64_t npix, int32_t C, void *stream);
 
 /* dsrc (+=, may be NULL) and dflow (+=, 2 channels, may be NULL) of dcvc_warp.  The source scatter is summed in
- * 64-bit fixed point (2^-36 steps) so that the result is independent of the order the atomics land in:
- * fix_scratch = N*H*W*C 8-byte words, ALL ZERO on entry, left all zero on return (required when dsrc != NULL). */
+ * 64-bit fixed point so that the result is independent of the order the atomics land in; the step is 2^-40 of the
+ * largest |dout| of THIS call (found by a first pass), so gradients of any magnitude keep ~fp32 relative accuracy, and
+ * a non-finite dout makes every dsrc element NaN instead of a clamped finite value:
+ * fix_scratch = N*H*W*C + 1 8-byte words, ALL ZERO on entry, left all zero on return (required when dsrc != NULL). */
 int dcvc_warp_bwd(const float *src, int32_t src_cs, const float *flow, int32_t flow_cs, const float *dout,
                   int32_t dout_cs, float *dsrc, int32_t dsrc_cs, float *dflow, int32_t dflow_cs, int32_t N, int32_t H,
                   int32_t W, int32_t C, void *fix_scratch, void *stream);

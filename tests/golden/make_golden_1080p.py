@@ -1,9 +1,10 @@
 """Generate tests/golden/seq_1088x1920.npz by running the REFERENCE itself at the bench size
-(build container only; ~2 minutes of CPU).
+(build container only; ~5 minutes of CPU).
 
 BASELINE configs[1] is quoted at 1920x1080 padded to 1088x1920 (stream_helper.get_padding_size), so
-this is the fixture that pins the benchmarked configuration to the reference: one I picture and two
-P pictures (the second one exercises the ref_feature / ref_y / ref_mv_y recursion,
+this is the fixture that pins the benchmarked configuration to the reference: one I picture and seven
+P pictures (from the second one on they exercise the ref_feature / ref_y / ref_mv_y recursion; seven since round 3:
+the growth of the deviation with depth in the GOP is asserted, tests/test_gpu_codec.py::test_bench_size_gop8_curve...,
 video_model.py:470-592, image_model.py:54-106) through the reference's estimate path with the
 name-seeded weights, frames from vcm_ts_amd/synthetic.py (1080 rows zero-padded at the bottom to
 1088 as video_coder.py:111-117 / pipeline.pad_frame do).
@@ -29,7 +30,7 @@ sys.path.insert(0, HERE)
 from make_golden import OUT, Tap, build_nets, crop, planes, stats  # noqa: E402
 from vcm_ts_amd.synthetic import frames  # noqa: E402
 
-H, W, SEED, N_P = 1080, 1920, 7, 2
+H, W, SEED, N_P = 1080, 1920, 7, 7
 
 
 def padded_frames():

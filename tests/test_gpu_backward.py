@@ -79,6 +79,35 @@ def test_conv_backward_fast_mode(eng_fast, case):
                        kw.pop("W"), seed=CONV_CASES.index(case), **kw) < 5e-5
 
 
+def test_warp_backward_propagates_a_non_finite_upstream_gradient(eng):
+    """The scatter of dcvc_warp_bwd sums in fixed point: a non-finite dout must not come out as a clamped finite
+    number (a diverged step would go unnoticed): every dsrc element becomes NaN, and the next call is clean again."""
+    import grad_check as G
+
+    N, C_, H, W = 1, 16, 12, 20
+    g = torch.Generator().manual_seed(3)
+    src, flow = torch.randn(N, C_, H, W, generator=g), torch.randn(N, 2, H, W, generator=g)
+    for poison in (float("inf"), None):
+        dout = torch.randn(N, C_, H, W, generator=g) * 1e-6
+        if poison is not None:
+            dout[0, 3, 5, 7] = poison
+        tape = G.Tape(eng)
+        eng.tape = tape
+        sv = eng.from_nchw(src.cuda(), eng.buf("wn.src", N, H, W, C_))
+        fv = eng.from_nchw(flow.cuda(), eng.buf("wn.flow", N, H, W, 2))
+        ov = eng.warp(sv, fv, eng.buf("wn.out", N, H, W, C_))
+        eng.tape = None
+        eng.from_nchw(dout.cuda(), tape.grad(ov))
+        tape.backward()
+        ds = eng.to_nchw(tape.grad(sv)).cpu()
+        if poison is not None:
+            assert torch.isnan(ds).all()
+        else:
+            sr = src.clone().requires_grad_()
+            G.R.warp(sr, flow).backward(dout)
+            assert G.rel(ds, sr.grad) < 2e-5
+
+
 def test_resampling_backward(eng):
     import grad_check as G
 

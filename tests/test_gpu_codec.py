@@ -204,6 +204,55 @@ def test_bench_size_matches_reference_fixture(nets):
     torch.cuda.empty_cache()
 
 
+def test_bench_size_gop8_curve_against_reference(nets):
+    """I + 7 P pictures at 1088x1920 against the reference's own run (tests/golden/seq_1088x1920.npz, extended to 7 P
+    pictures in round 3): how the deviation grows with depth in the GOP.  Per picture: relative deviation of bpp, mse
+    and PSNR from the reference, and the fraction of integer symbols that differ from the reference's planes (always by
+    +-1: rounding ties that fall the other way and cascade through the checkerboard and the DPB).  Asserted at EVERY
+    depth: bpp, bits, mse and PSNR within 1e-4 (north_star's tolerance on the totals); the curve itself is printed and
+    kept under profiles/ (r03_gop8_vs_reference.txt)."""
+    from vcm_ts_amd.pipeline import pad_frame
+
+    d, i = nets
+    fx = golden("seq_1088x1920")
+    n_p = max(int(k[1]) for k in fx.files if k.startswith("p") and k[1].isdigit() and k.endswith("_bpp"))
+    assert n_p >= 7
+    fr = frames(int(fx["seed"]), n_p + 1, int(fx["height"]), int(fx["width"]))
+    xs = [pad_frame(torch.from_numpy(fr[t : t + 1])).cuda() for t in range(n_p + 1)]
+    ri = i(xs[0], 1.0)
+    dpb = {"ref_frame": ri["x_hat"], "ref_feature": None, "ref_y": None, "ref_mv_y": None}
+    lines = [f"# {d.engine().precision}: picture, rel. deviation of bpp / mse / PSNR from the reference, differing symbols: motion, residual (fraction)"]
+    worst = 0.0
+    for t in range(1, n_p + 1):
+        v = d.compress(xs[t], dpb, 1.0, 1.0)["_views"]
+        report = {}
+        _plane_report({"sym_mv_y0": v["r_mv"]["sym"][0], "sym_mv_y1": v["r_mv"]["sym"][1], "sym_y0": v["r_y"]["sym"][0],
+                       "sym_y1": v["r_y"]["sym"][1]}, fx, f"p{t}_", report)
+        r = d.forward_one_frame(xs[t], dpb, 1.0, 1.0)
+        dpb = r["dpb"]
+        dev = {}
+        for k in ("bpp", "bit", "mse"):
+            got = float(r[k].reshape(-1)[0]) if torch.is_tensor(r[k]) else float(r[k])
+            want = float(np.asarray(fx[f"p{t}_{k}"]).reshape(-1)[0])
+            dev[k] = abs(got - want) / abs(want)
+        psnr_ref = 10 * np.log10(1.0 / float(fx[f"p{t}_mse"][0]))
+        dev["psnr"] = abs(10 * np.log10(1.0 / r["mse"].item()) - psnr_ref) / max(abs(psnr_ref), 1.0)
+        mv = sum(report[f"p{t}_sym_mv_y{h}"][0] for h in (0, 1)) / sum(report[f"p{t}_sym_mv_y{h}"][1] for h in (0, 1))
+        yy = sum(report[f"p{t}_sym_y{h}"][0] for h in (0, 1)) / sum(report[f"p{t}_sym_y{h}"][1] for h in (0, 1))
+        assert all(report[k][2] <= 1 for k in report), report  # every differing symbol is one step away
+        lines.append(f"P{t}: bpp {dev['bpp']:.1e}  mse {dev['mse']:.1e}  PSNR {dev['psnr']:.1e}   symbols: motion {mv:.2e}  residual {yy:.2e}")
+        worst = max(worst, dev["bpp"], dev["bit"], dev["mse"], dev["psnr"])
+        assert max(dev.values()) <= TOL, (t, dev)
+    print("\n" + "\n".join(lines))
+    out = os.environ.get("DCVC_CURVE_OUT")
+    if out:
+        with open(out, "a") as f:
+            f.write("\n".join(lines) + "\n")
+    d.engine().release()
+    i.engine().release()
+    torch.cuda.empty_cache()
+
+
 def test_batch_of_rate_points_matches_reference(nets):
     d, i = nets
     fx = golden("seq_64_b2")

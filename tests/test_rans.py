@@ -288,6 +288,9 @@ def test_index_bin_edges_reproduce_build_indexes():
     for dist, key in (("laplace", "idx_sweep_laplace"), ("gaussian", "idx_sweep_gauss")):
         edges = E.scale_index_edges(dist)
         assert edges.shape == (256,) and torch.isinf(edges[-1]) and bool((edges[1:] > edges[:-1]).all())
+        # the product path's edges are constants (vcm_ts_amd/index_edges.py): this host's torch-CPU logf must agree
+        # with them bit for bit, or its streams would not decode elsewhere
+        assert torch.equal(E.derive_scale_index_edges(dist).view(torch.int32), edges.view(torch.int32))
         count = lambda v: (edges[None, :] <= v[:, None]).sum(1).int()
         np.testing.assert_array_equal(count(s).numpy(), t[key])
         eb = edges[:-1].view(torch.int32)

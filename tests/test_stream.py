@@ -47,3 +47,21 @@ def test_pad_frame_matches_reference_padding():
     y = pad_frame(x)
     assert y.shape == (1, 3, 1088, 1920)
     assert torch.equal(y[..., :1080, :], x) and float(y[..., 1080:, :].abs().max()) == 0.0
+
+
+def test_rate_point_selection_matches_reference_interpolation():
+    """run_codec --rate-count / --quality (video_coder.py:181-197): interpolate_log against values the reference's
+    own function produced (tests/golden/make_golden_rate_points.py), and the anchor order of the q_scale tensors."""
+    from vcm_ts_amd.run_codec import interpolate_log, rate_point_q_scales
+
+    fx = golden("rate_points")
+    for k, (lo, hi, n) in enumerate(zip(fx["lo"], fx["hi"], fx["num"])):
+        np.testing.assert_array_equal(interpolate_log(float(lo), float(hi), int(n)), fx[f"dec_{k}"])
+        np.testing.assert_array_equal(interpolate_log(float(lo), float(hi), int(n), decending=False), fx[f"asc_{k}"])
+    # checkpoints store the anchors coarsest first: [0] is the maximum, [-1] the minimum (video_coder.py:183-184)
+    i_q, y_q, mv_q = np.array([1.8, 1.2, 0.8, 0.5]), np.array([2.7, 1.5, 0.9, 0.3]), np.array([12.0, 3.0, 1.0, 0.05])
+    q = rate_point_q_scales(i_q, y_q, mv_q, 6, 1)
+    assert q == (float(fx["dec_0"][1]), float(interpolate_log(0.05, 12.0, 6)[1]), float(interpolate_log(0.3, 2.7, 6)[1]))
+    assert rate_point_q_scales(i_q, y_q, mv_q, 6, 0) == (1.8, 12.0, 2.7)
+    with pytest.raises(ValueError):
+        rate_point_q_scales(i_q, y_q, mv_q, 6, 6)

@@ -664,20 +664,43 @@ __device__ __forceinline__ float lin11(int i, int n) {
     return i < n / 2 ? -1.0f + step * (float)i : 1.0f - step * (float)(n - 1 - i);
 }
 
-// Order-independent accumulation for the scatter of grid_sample's backward: contributions are rounded to
-// 2^-36 (range +-1.3e8: rate gradients reach 1e4) and added as integers.
-constexpr float FIX_ONE = 68719476736.f;  // 2^36
-__device__ __forceinline__ void fix_add(unsigned long long *p, float v) {
-    atomicAdd(p, (unsigned long long)__float2ll_rn(v * FIX_ONE));
+// Order-independent accumulation for the scatter of grid_sample's backward: contributions are scaled by a power of
+// two, rounded to integers and added with 64-bit integer atomics (associative: run-to-run identical).  The scale is
+// chosen PER CALL from max |dout| (an absolute 2^-36 quantum rounds feature-level gradients of 1e-9 at
+// 1e-2 relative): 2^40 / 2^ceil(log2 max), i.e. the largest contribution lands near 2^40 -- 2^21 of them (every
+// pixel of a 1080p picture sampling one source element) still fit 63 bits -- and the quantum is 2^-40 of the largest
+// upstream gradient whatever its magnitude.  A non-finite upstream gradient poisons the whole result with NaN instead
+// of being clamped to a finite integer.  The call's control word (fix[npix * C]): max |dout| bit pattern.
+__device__ __forceinline__ int fix_scale_exp(unsigned maxbits) {  // exponent se of the call's scale 2^se
+    const int e = (int)(maxbits >> 23) - 127;                      // floor(log2 max) for normal floats
+    return 39 - (e < -80 ? -80 : e);                               // (<= 119: the scale itself stays a finite float)
+}
+__device__ __forceinline__ void fix_add(unsigned long long *p, float v, float scale) {
+    atomicAdd(p, (unsigned long long)__float2ll_rn(v * scale));
+}
+
+__global__ void absmax_bits_kernel(const float *__restrict__ x, int x_cs, int64_t npix, int C, unsigned *__restrict__ word) {
+    unsigned m = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < npix * C; i += (int64_t)gridDim.x * blockDim.x)
+        m = max(m, __float_as_uint(x[(i / C) * x_cs + i % C]) & 0x7fffffffu);  // |x| orders like its bits; Inf / NaN on top
+    for (int o = 32; o >= 1; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(word, m);  // integer max: order-independent
 }
 
 __global__ void fix_finish_kernel(unsigned long long *__restrict__ fix, float *__restrict__ dst, int dst_cs, int64_t npix, int C) {
     const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= npix * C) return;
+    const unsigned maxbits = (unsigned)fix[npix * C];
     const long long v = (long long)fix[gid];
     fix[gid] = 0;  // left clean for the next call
-    if (v) dst[(gid / C) * dst_cs + gid % C] += (float)((double)v * (1.0 / 68719476736.0));
+    if (maxbits >= 0x7f800000u) {
+        dst[(gid / C) * dst_cs + gid % C] = __uint_as_float(0x7fc00000u);  // upstream gradient was not finite
+    } else if (v) {
+        dst[(gid / C) * dst_cs + gid % C] += (float)ldexp((double)v, -fix_scale_exp(maxbits));
+    }
 }
+
+__global__ void fix_reset_kernel(unsigned long long *word) { *word = 0; }
 
 // One thread per (pixel, channel group): scatter into dsrc with integer atomics, reduce the flow gradient over the Cl
 // lanes of a pixel (consecutive lanes of one wave) with a shuffle butterfly.  Round 2: this reduction used to go through
@@ -699,6 +722,11 @@ __global__ void warp_bwd_kernel(const float *__restrict__ src, int src_cs, const
     const int64_t pix = (int64_t)blockIdx.x * blockDim.y + threadIdx.y;  // blockDim = (Cl, 256 / Cl)
     const bool live = pix < (int64_t)N * H * W;
     float gx_acc = 0.f, gy_acc = 0.f;
+    float fscale = 0.f;  // this call's fixed-point scale (0: a non-finite upstream gradient, fix_finish writes NaN)
+    if (dsrc) {
+        const unsigned maxbits = (unsigned)fix[(int64_t)N * H * W * C];
+        if (maxbits < 0x7f800000u) fscale = ldexpf(1.f, fix_scale_exp(maxbits));
+    }
     if (live) {
         const int x = (int)(pix % W), y = (int)((pix / W) % H);
         const int64_t n = pix / ((int64_t)W * H);
@@ -729,10 +757,10 @@ __global__ void warp_bwd_kernel(const float *__restrict__ src, int src_cs, const
                 // the scatter is data dependent (several output pixels may sample one source pixel): summed as
                 // 64-bit fixed point, whose addition is associative, so the result does not depend on the order
                 // in which the atomics land (float atomics made two runs of the same step differ in the last bits)
-                fix_add(&fix[pnw * C + c], g * (s * e));
-                if (x1in) fix_add(&fix[pne * C + c], g * (s * w));
-                if (y1in) fix_add(&fix[psw * C + c], g * (nn * e));
-                if (x1in && y1in) fix_add(&fix[pse * C + c], g * (nn * w));
+                fix_add(&fix[pnw * C + c], g * (s * e), fscale);
+                if (x1in) fix_add(&fix[pne * C + c], g * (s * w), fscale);
+                if (y1in) fix_add(&fix[psw * C + c], g * (nn * e), fscale);
+                if (x1in && y1in) fix_add(&fix[pse * C + c], g * (nn * w), fscale);
             }
         }
         gx_acc *= mx;
@@ -1236,7 +1264,8 @@ extern "C" int dcvc_conv_wgrad(const dcvc_conv_wgrad_args *a, void *stream) {
     if (a->db) k.bscratch = a->scratch + (size_t)splits * nct * k.T * 1024;
     hipStream_t st = (hipStream_t)stream;
     dim3 grid((unsigned)splits, (unsigned)nct, (unsigned)groups);
-    const bool split = a->precision == DCVC_PREC_FP16X3 && a->stride == 1;  // fast mode: bf16 hi/lo operands
+    // fast mode: bf16 hi/lo operands.  wgrad_bf16_kernel indexes dpre at (oy, ox): only without zero insertion (zs == 1)
+    const bool split = a->precision == DCVC_PREC_FP16X3 && a->stride == 1 && a->zs == 1;
     if (split && a->ks == 3) hipLaunchKernelGGL((wgrad_bf16_kernel<3>), grid, dim3(256), 0, st, k);
     else if (split && a->ks == 7) hipLaunchKernelGGL((wgrad_bf16_kernel<7>), grid, dim3(256), 0, st, k);
     else if (split) hipLaunchKernelGGL((wgrad_bf16_kernel<1>), grid, dim3(256), 0, st, k);
@@ -1293,11 +1322,19 @@ extern "C" int dcvc_warp_bwd(const float *src, int32_t src_cs, const float *flow
     while (Cl * 2 <= C && Cl < 64) Cl *= 2;  // threads per pixel (power of two <= 64)
     const int64_t npix = (int64_t)N * H * W;
     dim3 block(Cl, 256 / Cl);
+    unsigned long long *fix = (unsigned long long *)fix_scratch;
+    if (dsrc) {
+        const int64_t nb = nblk(npix * C, 256 * 8);
+        hipLaunchKernelGGL(absmax_bits_kernel, dim3((unsigned)(nb < 1024 ? nb : 1024)), dim3(256), 0, (hipStream_t)stream, dout,
+                           dout_cs, npix, C, (unsigned *)(fix + npix * C));
+    }
     hipLaunchKernelGGL(warp_bwd_kernel, dim3(nblk(npix, 256 / Cl)), block, 0, (hipStream_t)stream, src, src_cs, flow,
-                       flow_cs, dout, dout_cs, dsrc, dsrc_cs, dflow, dflow_cs, N, H, W, C, (unsigned long long *)fix_scratch);
-    if (dsrc)
-        hipLaunchKernelGGL(fix_finish_kernel, dim3(nblk(npix * C, 256)), dim3(256), 0, (hipStream_t)stream,
-                           (unsigned long long *)fix_scratch, dsrc, dsrc_cs, npix, C);
+                       flow_cs, dout, dout_cs, dsrc, dsrc_cs, dflow, dflow_cs, N, H, W, C, fix);
+    if (dsrc) {
+        hipLaunchKernelGGL(fix_finish_kernel, dim3(nblk(npix * C, 256)), dim3(256), 0, (hipStream_t)stream, fix, dsrc, dsrc_cs,
+                           npix, C);
+        hipLaunchKernelGGL(fix_reset_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, fix + npix * C);
+    }
     RET_LAUNCH();
 }
 

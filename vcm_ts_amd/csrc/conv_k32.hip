@@ -76,6 +76,7 @@ struct K32 {
     int *status;
     float *chan_partial;
     int ntx;
+    int ty0, nty, band_rows;  // band of tile rows this launch computes (dcvc_conv_args.tile_row0 / tile_rows)
 };
 
 __device__ __forceinline__ float act(float v, float slope) { return v > 0.f ? v : v * slope; }
@@ -94,7 +95,8 @@ __global__ __launch_bounds__(256, 2) void conv_k32(const K32 a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nbn = a.Cout_pad / BN;
     const int nb = blockIdx.x % nbn, tx = blockIdx.x / nbn;
-    const int x0 = tx * BW, y0 = blockIdx.y * BH, n0 = nb * BN, img = blockIdx.z;
+    const int ty = blockIdx.y + a.ty0;
+    const int x0 = tx * BW, y0 = ty * BH, n0 = nb * BN, img = blockIdx.z;
 
     f32x4 acc[4][NTW];
 #pragma unroll
@@ -348,7 +350,7 @@ __global__ __launch_bounds__(256, 2) void conv_k32(const K32 a) {
         __syncthreads();
         if (tid < BN && n0 + tid < a.Cout_pad) {
             const float s = ((red[tid] + red[BN + tid]) + red[2 * BN + tid]) + red[3 * BN + tid];
-            const size_t part = (size_t)img * (gridDim.y * a.ntx) + (size_t)blockIdx.y * a.ntx + tx;
+            const size_t part = (size_t)img * (a.nty * a.ntx) + (size_t)ty * a.ntx + tx;
             a.chan_partial[part * a.Cout_pad + n0 + tid] = s;
         }
     }
@@ -358,7 +360,10 @@ template <int KS, int NTW>
 int launch(K32 &k, int N, hipStream_t st) {
     constexpr int BN = 16 * NTW;
     k.ntx = (k.W + 31) / 32;
-    dim3 grid((unsigned)(k.ntx * (k.Cout_pad / BN)), (unsigned)((k.H + 7) / 8), (unsigned)N);
+    k.nty = (k.H + 7) / 8;
+    if (k.ty0 < 0 || k.ty0 >= k.nty) return DCVC_E_ARG;
+    const int rows = k.band_rows > 0 ? (k.band_rows < k.nty - k.ty0 ? k.band_rows : k.nty - k.ty0) : k.nty;
+    dim3 grid((unsigned)(k.ntx * (k.Cout_pad / BN)), (unsigned)rows, (unsigned)N);
     hipLaunchKernelGGL((conv_k32<KS, NTW>), grid, dim3(256), 0, st, k);
     return hipGetLastError() == hipSuccess ? DCVC_OK : DCVC_E_LAUNCH;
 }
@@ -452,6 +457,8 @@ extern "C" int dcvc_conv2d_k32(const dcvc_conv_args *a, void *stream) {
     k.res2_cs = a->res2_cs;
     k.status = a->status;
     k.chan_partial = a->chan_partial;
+    k.ty0 = a->tile_rows > 0 ? a->tile_row0 : 0;
+    k.band_rows = a->tile_rows > 0 ? a->tile_rows : 0;
     const int cfin = a->pixel_shuffle ? a->Cout / 4 : a->Cout;
     // this kernel has the 16-byte epilogue only (every layer it is meant for qualifies); others stay on dcvc_conv2d
     if ((cfin % 4) || !aligned16(a->out, a->out_cs) || !aligned16(a->res, a->res_cs) || !aligned16(a->res2, a->res2_cs) ||

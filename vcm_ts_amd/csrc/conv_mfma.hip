@@ -76,6 +76,8 @@ struct ConvK {
     int *status;  // optional: flag outputs a split-fp16 consumer would clamp
     float *chan_partial;  // optional: per-workgroup channel sums of the stored output (SE layer)
     int ntx;              // tiles per row (gridDim.x may be padded, see launch())
+    int ty0, nty;         // first tile row of this launch's band, tile rows of the whole picture
+    int band_rows;        // tile rows of the band (0: all)
 };
 
 constexpr float ACT_LIMIT = 65504.f / 8.f;  // F16_MAX / ACT_SCALE
@@ -107,7 +109,8 @@ __global__ __launch_bounds__(256, 2) void conv_mfma(const ConvK a) {
     const int nbn = a.Cout_pad / BN;
     const int nb = blockIdx.x % nbn, tx = blockIdx.x / nbn;
     if (tx >= a.ntx) return;  // padding block of launch(): keeps vertically adjacent tiles on one XCD
-    const int x0 = tx * BW, y0 = blockIdx.y * BH, n0 = nb * BN, img = blockIdx.z;
+    const int ty = blockIdx.y + a.ty0;
+    const int x0 = tx * BW, y0 = ty * BH, n0 = nb * BN, img = blockIdx.z;
 
     f32x16 acc[RPW][NT];
 #pragma unroll
@@ -384,7 +387,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma(const ConvK a) {
             __syncthreads();
             if (tid < BN && n0 + tid < a.Cout_pad) {
                 const float s = ((red[tid] + red[BN + tid]) + red[2 * BN + tid]) + red[3 * BN + tid];
-                const size_t part = (size_t)img * (gridDim.y * a.ntx) + (size_t)blockIdx.y * a.ntx + tx;
+                const size_t part = (size_t)img * (a.nty * a.ntx) + (size_t)ty * a.ntx + tx;
                 a.chan_partial[part * a.Cout_pad + n0 + tid] = s;
             }
         }
@@ -451,7 +454,10 @@ int launch(ConvK &k, int N, hipStream_t st, int precision) {
     static const bool xcd_pad = getenv("DCVC_XCD_PAD") ? atoi(getenv("DCVC_XCD_PAD")) != 0 : false;
     unsigned gx = (unsigned)(k.ntx * (k.Cout_pad / BN));
     if (xcd_pad && gx >= 8) gx = (gx + 7) & ~7u;
-    dim3 grid(gx, (unsigned)((k.Hout + BH - 1) / BH), (unsigned)N);
+    k.nty = (k.Hout + BH - 1) / BH;
+    if (k.ty0 < 0 || k.ty0 >= k.nty) return DCVC_E_ARG;
+    const int rows = k.band_rows > 0 ? (k.band_rows < k.nty - k.ty0 ? k.band_rows : k.nty - k.ty0) : k.nty;
+    dim3 grid(gx, (unsigned)rows, (unsigned)N);
     if (precision == DCVC_PREC_FP16X3)
         hipLaunchKernelGGL((conv_mfma<KS, S, RPW, NT, true>), grid, dim3(256), 0, st, k);
     else
@@ -526,6 +532,8 @@ extern "C" int dcvc_conv_pack_weights(const float *w, const float *b, int32_t Co
 // rows of a workgroup's output tile per (kernel size, stride): 4 * RPW of the instantiations below
 static int tile_rows(int ks, int stride) { return stride == 2 ? 4 : 8; }
 
+extern "C" int32_t dcvc_conv_tile_rows(int32_t ks, int32_t stride) { return tile_rows(ks, stride); }
+
 extern "C" int32_t dcvc_conv_chan_partial_parts(int32_t ks, int32_t stride, int32_t Hout, int32_t Wout) {
     if (Hout <= 0 || Wout <= 0 || (stride != 1 && stride != 2)) return DCVC_E_ARG;
     const int bh = tile_rows(ks, stride);
@@ -571,6 +579,8 @@ extern "C" int dcvc_conv2d(const dcvc_conv_args *a, void *stream) {
     k.res2_cs = a->res2_cs;
     k.status = a->status;
     k.chan_partial = a->chan_partial;
+    k.ty0 = a->tile_rows > 0 ? a->tile_row0 : 0;
+    k.band_rows = a->tile_rows > 0 ? a->tile_rows : 0;
     {
         const int cfin = a->pixel_shuffle ? a->Cout / 4 : a->Cout;
         auto al = [](const void *p, int cs) { return p == nullptr || ((((uintptr_t)p) & 15) == 0 && (cs & 3) == 0); };

@@ -273,6 +273,7 @@ extern "C" int dcvc_conv_small_pack_weights(const float *w, const float *b, int3
 // no second residual, no chan_partial; wpack / bpack from dcvc_conv_small_pack_weights; DCVC_PREC_FP16X3.
 extern "C" int dcvc_conv2d_small(const dcvc_conv_args *a, void *stream) {
     if (!a || a->nseg < 1 || a->nseg > DCVC_MAX_SEG || !a->out || !a->wpack || !a->bpack) return DCVC_E_ARG;
+    if (a->tile_rows > 0) return DCVC_E_ARG;  // no banded launches for this kernel
     if (a->Cout <= 0 || a->Cout > 16 || (a->ks != 3 && a->ks != 7) || a->stride != 1 || a->pixel_shuffle || a->res_gate ||
         a->res2 || a->chan_partial || a->precision != DCVC_PREC_FP16X3 || a->N <= 0)
         return DCVC_E_ARG;

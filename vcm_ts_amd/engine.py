@@ -409,11 +409,11 @@ class Engine:
                 and stride == 1 and not pk.ps and gate is None and res2 is None and chan_partial is None)
 
     def conv(self, pk: PackedConv, srcs, out: View, stride=1, in_slope=None, out_slope=None, res: View = None,
-             gate: torch.Tensor = None, res2: View = None, chan_partial: torch.Tensor = None):
+             gate: torch.Tensor = None, res2: View = None, chan_partial: torch.Tensor = None, band=None):
         """chan_partial: buffer from chan_partial_buf() that receives the per-workgroup channel sums of the output
         (fused SE squeeze).  Which kernel serves the layer (conv_mfma / conv_k32 / conv_small) is decided in
         _conv_f32 from the layer's geometry alone, so an encoder and its decoder always agree."""
-        return self._conv_f32(pk, srcs, out, stride, in_slope, out_slope, res, gate, res2, chan_partial)
+        return self._conv_f32(pk, srcs, out, stride, in_slope, out_slope, res, gate, res2, chan_partial, band)
 
     def _launch_conv(self, launch, pk, s0, Ho, Wo, stride, res, res2, tag="", note=""):
         if self.profile is None:
@@ -441,7 +441,9 @@ class Engine:
         return self.fbuf(name + ".chan_partial", out.N * parts * pk.Cout_pad), parts
 
     def _conv_f32(self, pk: PackedConv, srcs, out: View, stride=1, in_slope=None, out_slope=None, res: View = None,
-                  gate: torch.Tensor = None, res2: View = None, chan_partial: torch.Tensor = None):
+                  gate: torch.Tensor = None, res2: View = None, chan_partial: torch.Tensor = None, band=None):
+        """band = (first tile row, tile rows): compute only that band of output rows (dcvc_conv_args.tile_row0 /
+        tile_rows; a tile row is dcvc_conv_tile_rows(ks, stride) output rows)."""
         a = lib.ConvArgs()
         assert len(srcs) == len(pk.seg_C)
         s0 = srcs[0]
@@ -450,7 +452,7 @@ class Engine:
             a.seg[i].ptr, a.seg[i].C, a.seg[i].cs = s.ptr, s.C, s.cs
         a.nseg, a.N, a.Hin, a.Win = len(srcs), s0.N, s0.H, s0.W
         a.in_act, a.in_slope = (0, 0.0) if in_slope is None else (1, in_slope)
-        small = self.small_capable(pk, stride, gate, res2, chan_partial)
+        small = band is None and self.small_capable(pk, stride, gate, res2, chan_partial)
         k32 = not small and self.k32_capable(pk, stride, out, res, res2, gate)
         wq = self.pack_small(pk) if small else (self.pack_k32(pk) if k32 else pk)
         a.wpack, a.bpack = wq.w.data_ptr(), wq.b.data_ptr()
@@ -477,6 +479,8 @@ class Engine:
             a.status = self.status_word().data_ptr()
         if chan_partial is not None:
             a.chan_partial = chan_partial.data_ptr()
+        if band is not None:
+            a.tile_row0, a.tile_rows = int(band[0]), int(band[1])
         fn, what = (self.L.dcvc_conv2d_small, "conv2d_small") if small else (
             (self.L.dcvc_conv2d_k32, "conv2d_k32") if k32 else (self.L.dcvc_conv2d, "conv2d"))
         note = ""

@@ -169,11 +169,23 @@ _EDGE_CACHE = {}
 def scale_index_edges(distribution: str) -> torch.Tensor:
     """(256,) fp32: edge[k-1] = the smallest fp32 scale whose reference index is >= k (k = 1..255),
     edge[255] = +inf, so that index(s) = #{edges <= s} reproduces build_indexes bit for bit without a
-    device logarithm (the kernels' logf differs from torch-CPU's by an ulp next to a bin edge).  Found
-    by bisection over the float's bit pattern -- positive floats order like their int32 bits -- with
-    the reference formula itself, all 255 edges at once."""
-    if distribution in _EDGE_CACHE:
-        return _EDGE_CACHE[distribution]
+    device logarithm (the kernels' logf differs from torch-CPU's by an ulp next to a bin edge).
+    The values are CONSTANTS (vcm_ts_amd/index_edges.py): every host bins alike, whatever its libm;
+    derive_scale_index_edges() is how they were found and how a test re-checks them."""
+    if distribution not in _EDGE_CACHE:
+        from . import index_edges
+
+        bits = {"laplace": index_edges.LAPLACE_EDGE_BITS, "gaussian": index_edges.GAUSSIAN_EDGE_BITS}[distribution]
+        assert len(bits) == SCALE_LEVELS - 1
+        edges = torch.tensor(list(bits) + [0x7F800000], dtype=torch.int32).view(torch.float32).clone()
+        _EDGE_CACHE[distribution] = edges
+    return _EDGE_CACHE[distribution]
+
+
+def derive_scale_index_edges(distribution: str) -> torch.Tensor:
+    """The edges of scale_index_edges() re-derived on this host: bisection over the float's bit pattern -- positive
+    floats order like their int32 bits -- with the reference formula itself (reference_scale_indexes: torch-CPU
+    logf), all 255 edges at once; monotonicity checked on both sides of every edge."""
     k = torch.arange(1, SCALE_LEVELS + 1, dtype=torch.int32)          # 256 lanes; the last is a dummy
     lo = torch.full((SCALE_LEVELS,), 1e-5, dtype=torch.float32).view(torch.int32).clone()    # index 0 < k
     hi = torch.full((SCALE_LEVELS,), 128.0, dtype=torch.float32).view(torch.int32).clone()   # index 255
@@ -184,14 +196,12 @@ def scale_index_edges(distribution: str) -> torch.Tensor:
         lo = torch.where(ge, lo, mid)
     edges = hi.view(torch.float32).clone()
     edges[SCALE_LEVELS - 1] = float("inf")
-    # the construction assumes a monotone index; verify it on both sides of every edge
     below = (hi - 1).view(torch.float32).clone()
     kk = k[:-1]
     if not (torch.equal(reference_scale_indexes(edges[:-1].clone(), distribution), kk)
             and torch.equal(reference_scale_indexes(below[:-1], distribution), kk - 1)
             and bool((edges[1:] > edges[:-1]).all())):
         raise RansError("build_indexes is not a monotone step function on this host; bin edges undefined")
-    _EDGE_CACHE[distribution] = edges
     return edges
 
 

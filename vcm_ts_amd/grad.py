@@ -206,7 +206,6 @@ class Tape:
                 w.scratch, w.scratch_floats = sc.data_ptr(), sc.numel()
                 w.overwrite = int(whole)
                 w.precision = lib.PRECISIONS[e.precision] if e.wgrad_split else lib.PRECISIONS["fp32"]
-                w.precision = lib.PRECISIONS[e.precision] if e.wgrad_split else lib.PRECISIONS["fp32"]
                 if db is not None and si == 0:  # the bias gradient rides on the first segment's pass over dY
                     w.db = db.data_ptr()
                 lib.check(L.dcvc_conv_wgrad(C.byref(w), wstream), "conv_wgrad")
@@ -237,7 +236,7 @@ class Tape:
             return
         fix = None
         if dsrc is not None:  # zeroed once; the kernels hand it back clean
-            n = src.N * src.H * src.W * src.C
+            n = src.N * src.H * src.W * src.C + 1  # + the call's control word (dcvc_hip_grad.h)
             fix = getattr(self.e, "_fix_scratch", None)  # lives with the engine: launches on one stream reuse it in order
             if fix is None or fix.numel() < n:
                 fix = self.e._fix_scratch = torch.zeros(n, dtype=torch.int64, device=self.e.device)

@@ -70,7 +70,7 @@ class ConvArgs(C.Structure):
         ("out", C.c_void_p), ("out_cs", C.c_int32), ("out_act", C.c_int32), ("out_slope", C.c_float),
         ("pixel_shuffle", C.c_int32), ("res", C.c_void_p), ("res_cs", C.c_int32), ("res_gate", C.c_void_p),
         ("res2", C.c_void_p), ("res2_cs", C.c_int32), ("precision", C.c_int32), ("status", C.c_void_p),
-        ("chan_partial", C.c_void_p),
+        ("chan_partial", C.c_void_p), ("tile_row0", C.c_int32), ("tile_rows", C.c_int32),
     ]
 
 
@@ -189,7 +189,7 @@ _SIGS = {
     "dcvc_drans_build_lut": [vp, i32, i32, vp, vp],
 }
 
-HIP_SYMBOLS = sorted(list(_SIGS) + ["dcvc_cdf_table_cols", "dcvc_conv_pack_size", "dcvc_conv_small_pack_bytes", "dcvc_conv_k32_pack_bytes", "dcvc_conv_chan_partial_parts", "dcvc_hip_version", "dcvc_conv_wgrad_scratch_min",
+HIP_SYMBOLS = sorted(list(_SIGS) + ["dcvc_cdf_table_cols", "dcvc_conv_pack_size", "dcvc_conv_small_pack_bytes", "dcvc_conv_k32_pack_bytes", "dcvc_conv_tile_rows", "dcvc_conv_chan_partial_parts", "dcvc_hip_version", "dcvc_conv_wgrad_scratch_min",
                                     "dcvc_drans_default_lanes", "dcvc_drans_scratch_words"])
 RANS_SYMBOLS = [
     "dcvc_rans_encoder_create", "dcvc_rans_encoder_destroy", "dcvc_rans_encoder_reset",
@@ -216,6 +216,8 @@ def hip():
         L.dcvc_conv_chan_partial_parts.restype = i32
         L.dcvc_conv_small_pack_bytes.argtypes = [i32, i32, i32, vp]
         L.dcvc_conv_small_pack_bytes.restype = i64
+        L.dcvc_conv_tile_rows.argtypes = [i32, i32]
+        L.dcvc_conv_tile_rows.restype = i32
         L.dcvc_conv_k32_pack_bytes.argtypes = [i32, i32, i32, vp, C.POINTER(i32)]
         L.dcvc_conv_k32_pack_bytes.restype = i64
         L.dcvc_hip_version.restype = C.c_char_p

@@ -28,9 +28,10 @@ def shard_gops(n_gops: int, rank: int, world: int):
     return [g for g in range(n_gops) if g % world == rank]
 
 
-def timed_region(fn, device=None):
+def timed_region(fn, device=None, with_local=False):
     """Run fn() between barriers and return the slowest rank's wall time in seconds (what
-    bench.py reports): barrier + device sync on both sides, MAX over ranks."""
+    bench.py reports): barrier + device sync on both sides, MAX over ranks.  with_local: also this
+    rank's own time, as a third value."""
     import time
 
     import torch.distributed as dist
@@ -47,13 +48,13 @@ def timed_region(fn, device=None):
     t0 = time.time()
     result = fn()
     fence()
-    dt = time.time() - t0
+    dt = local = time.time() - t0
     if multi:
         on_gpu = device is not None and dist.get_backend() == "nccl"
         t = torch.tensor([dt], dtype=torch.float64, device=device if on_gpu else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    return dt, result
+    return (dt, result, local) if with_local else (dt, result)
 
 
 class GopEncoder:

@@ -60,6 +60,26 @@ def _nets(device, precision, i_ckpt=None, p_ckpt=None):
     return i_net.to(device).eval(), p_net.to(device).eval()
 
 
+def interpolate_log(min_val, max_val, num, decending=True):
+    """DCVC_HEM/src/utils/common.py:23-31: `num` values spaced evenly in log(q) between the two anchors."""
+    import numpy as np
+
+    assert max_val > min_val > 0
+    lo, hi = np.log(min_val), np.log(max_val)
+    return np.exp(np.linspace(hi, lo, num) if decending else np.linspace(lo, hi, num))
+
+
+def rate_point_q_scales(i_q_scales, y_q_scales, mv_y_q_scales, rate_count, quality):
+    """video_coder.py:181-197: the (I, mv_y, y) q-scales of rate point `quality` out of `rate_count` points interpolated
+    in log space between the first (coarsest) and the last (finest) anchor a model was trained with.  The arguments
+    are the flattened q_scale tensors of the checkpoints (IntraNoAR.get_q_scales_from_ckpt / DMC.get_q_scales_from_ckpt)
+    or of the live modules.  Returns (q_i, q_mv_y, q_y) in the order encode_folder takes them."""
+    if not 0 <= quality < rate_count:
+        raise ValueError(f"quality must be in [0, {rate_count})")
+    pick = lambda qs: float(interpolate_log(float(qs[-1]), float(qs[0]), rate_count)[quality])
+    return pick(i_q_scales), pick(mv_y_q_scales), pick(y_q_scales)
+
+
 def encode_folder(frames_dir, bin_dir, recon_dir=None, gop=32, q=(1.0, 1.0, 1.0), device="cuda:0", precision=None,
                   i_ckpt=None, p_ckpt=None, max_frames=None, coder="host"):
     """Returns (bits per frame list, (height, width)).  coder="device": payloads in the opt-in GPU
@@ -135,7 +155,12 @@ def main():
     e.add_argument("--frames", required=True)
     e.add_argument("--bins", required=True)
     e.add_argument("--recon")
-    e.add_argument("--q", type=float, nargs=3, default=(1.0, 1.0, 1.0), metavar=("I", "MV_Y", "Y"))
+    e.add_argument("--q", type=float, nargs=3, default=None, metavar=("I", "MV_Y", "Y"),
+                   help="explicit q-scales (default 1 1 1 when no rate point is selected)")
+    e.add_argument("--rate-count", type=int, default=None,
+                   help="with --quality: the reference's rate-point selection (video_coder.py RATE_COUNT / QUALITY): "
+                        "q-scales interpolated in log space between the anchors stored in the checkpoints")
+    e.add_argument("--quality", type=int, default=None)
     e.add_argument("--coder", default="host", choices=["host", "device"],
                    help="host: the reference's bitstream (default); device: opt-in GPU entropy coder, own format")
     d = sub.add_parser("decode")
@@ -151,7 +176,24 @@ def main():
         p.add_argument("--p-ckpt")
     a = ap.parse_args()
     if a.cmd == "encode":
-        bits, size = encode_folder(a.frames, a.bins, a.recon, a.gop, tuple(a.q), a.device, a.precision, a.i_ckpt, a.p_ckpt,
+        if (a.rate_count is None) != (a.quality is None) or (a.q is not None and a.rate_count is not None):
+            ap.error("give either --q, or --rate-count together with --quality")
+        q = tuple(a.q) if a.q is not None else (1.0, 1.0, 1.0)
+        if a.rate_count is not None:
+            from .dmc import DMC
+            from .intra import IntraNoAR
+            from .params import dmc_spec, intra_spec, seeded_state_dict
+
+            if a.i_ckpt and a.p_ckpt:
+                i_qs = IntraNoAR.get_q_scales_from_ckpt(a.i_ckpt)
+                y_qs, mv_qs = DMC.get_q_scales_from_ckpt(a.p_ckpt)
+            else:  # no checkpoint: the anchors of the name-seeded synthetic weights the nets are built with
+                i_qs = seeded_state_dict(intra_spec())["q_scale"].reshape(-1)
+                sd = seeded_state_dict(dmc_spec())
+                y_qs, mv_qs = sd["y_q_scale"].reshape(-1), sd["mv_y_q_scale"].reshape(-1)
+            q = rate_point_q_scales(i_qs, y_qs, mv_qs, a.rate_count, a.quality)
+            print(f"rate point {a.quality} of {a.rate_count}: q_i {q[0]:.4f}  q_mv_y {q[1]:.4f}  q_y {q[2]:.4f}")
+        bits, size = encode_folder(a.frames, a.bins, a.recon, a.gop, q, a.device, a.precision, a.i_ckpt, a.p_ckpt,
                                    coder=a.coder)
         print(f"{len(bits)} pictures, {size[0]}x{size[1]}, {sum(bits)} bits, {sum(bits) / (len(bits) * size[0] * size[1]):.4f} bpp")
     else:
