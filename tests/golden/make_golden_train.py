@@ -5,7 +5,8 @@ Two consecutive P pictures of a 64x64 batch-2 clip: the first after an "I pictur
 only ref_frame), the second with the full (detached) DPB -- the reference's `single` training
 recursion (core/model/dcvc_hem.py:189-196).  Stored: the uniform draws add_noise made (so that
 a checker can replay them), every scalar output, the loss and, per parameter, the gradient's
-L2 norm and its first 8 values; gradients of the per-sample q-scales in full.
+L2 norm and its first 8 values, the ten largest gradients in full (unit vectors, fp16); gradients of the per-sample
+q-scales in full.
 
 train_256_b4 is BASELINE configs[2]'s shape: batch 4 of 256x256 pictures, one rate point per sample (the
 model's first four q-scales, lambdas 85 / 170 / 380 / 840 as core/config/defaults.py).
@@ -90,6 +91,14 @@ def main(N=2, size=64, out_name="train_64", lambdas=None):
         fx[p + "grad_names"] = np.array([n for n, _ in net.named_parameters()])
         fx[p + "grad_norm"] = np.array(norms, np.float64)
         fx[p + "grad_head"] = np.stack(heads)
+        # directions, not only lengths: the ten tensors that carry most of the gradient, in full, as unit
+        # vectors in fp16 (the norm is stored above; fp16 keeps a cosine to ~1e-7)
+        named = list(net.named_parameters())
+        top = sorted(range(len(named)), key=lambda j: -norms[j])[:10]
+        fx[p + "grad_full_index"] = np.array(top, np.int64)
+        for j in top:
+            g = named[j][1].grad.double()
+            fx[p + f"grad_full_{j}"] = (g / g.norm()).reshape(-1).numpy().astype(np.float16)
         dpb = {k: v.detach() for k, v in out["dpb"].items()}
         print(f"step {step}: loss {loss.item():.6f}, {sum(n >= 0 for n in norms)} parameter gradients")
     np.savez_compressed(os.path.join(OUT, out_name + ".npz"), **fx)

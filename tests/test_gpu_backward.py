@@ -200,6 +200,17 @@ def test_frame_gradients_match_reference_fixture(name):
         print(f"\n[{fx_name} step {step}] gradient norms vs the reference: whole {sq_diff ** 0.5 / sq_ref ** 0.5:.2e}, "
               f"worst tensor {worst[0]} {worst[1]:.2e}")
         assert sq_diff ** 0.5 <= 2e-3 * sq_ref ** 0.5
+        # directions (round 3): the ten tensors with the largest gradients are stored in full (unit vectors); the norms
+        # above say nothing about where a gradient points
+        cos_worst = ("", 1.0)
+        for j in fx[p + "grad_full_index"]:
+            want_u = fx[p + f"grad_full_{int(j)}"].astype(np.float64)
+            g = params[names[int(j)]].grad.double().reshape(-1).cpu().numpy()
+            cos = float(g @ want_u / (np.linalg.norm(g) * np.linalg.norm(want_u)))
+            if cos < cos_worst[1]:
+                cos_worst = (names[int(j)], cos)
+        print(f"[{fx_name} step {step}] smallest cosine to the reference over the ten largest gradients: {cos_worst[0]} {cos_worst[1]:.7f}")
+        assert cos_worst[1] >= 0.9999, cos_worst
         dpb = {k: v.detach() for k, v in out["dpb"].items()}
     m._noise_override = None
 

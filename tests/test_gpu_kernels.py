@@ -177,7 +177,7 @@ def test_k32_conv_matches_fp64_and_the_32x32_kernel(eng_split, case):
     segs, cout, H, W, N, ps, in_slope, out_slope, use_res, use_gate, use_res2, in_cs = case[:12]
     ks = case[12] if len(case) > 12 else 3
     eng = eng_split
-    eng.k32_sizes = (1, 3)  # (1x1 layers are not routed to this kernel by default; the kernel covers them)
+    eng.k32_sizes, eng.k32_everywhere = (1, 3), True  # (the engine routes only large 3x3 layers to it; the kernel covers more)
     g = torch.Generator().manual_seed(K32_CASES.index(case) + 90)
     cin = sum(segs)
     mag = torch.tensor([1e-3, 1.0, 20.0])[torch.randint(0, 3, (N, cin, 1, 1), generator=g)]
@@ -227,7 +227,7 @@ def test_k32_conv_matches_fp64_and_the_32x32_kernel(eng_split, case):
                 outs[k32] = got
     finally:
         eng.use_k32 = True
-        eng.k32_sizes = (3,)
+        eng.k32_sizes, eng.k32_everywhere = (3,), False
     assert eng.read_status() == 0
     o1, o0 = outs[True].cpu().double(), outs[False].cpu().double()
     assert not torch.isnan(o1).any()
@@ -243,8 +243,12 @@ def test_k32_conv_flags_outputs_beyond_the_split_fp16_range(eng_split):
     pk = eng.pack(("k32sat",), torch.nn.Parameter(w.cuda()), torch.nn.Parameter(torch.zeros(32).cuda()), (32,), False)
     out = eng.buf("k32/sat", 1, 16, 32, 32)
     assert eng.read_status() == 0
-    eng.conv(pk, [to_view(eng, "k32/satin", x)], out)
-    assert eng.k32_capable(pk, 1, out, None, None, None)
+    eng.k32_everywhere = True
+    try:
+        assert eng.k32_capable(pk, 1, out, None, None, None)
+        eng.conv(pk, [to_view(eng, "k32/satin", x)], out)
+    finally:
+        eng.k32_everywhere = False
     assert eng.read_status() & 1
     assert eng.read_status() == 0
 

@@ -61,3 +61,7 @@ def test_training_forward_and_gradients_match_reference(name):
                                        err_msg=name)
             worst = max(worst, abs(got - want) / (want + 1e-30))
         print(f"step {step}: worst relative gradient-norm difference {worst:.2e}")
+        for j in fx[p + "grad_full_index"]:  # the ten largest gradients in full: directions (fp16 unit vectors)
+            want_u = fx[p + f"grad_full_{int(j)}"].astype(np.float64)
+            g = w[names[int(j)]].grad.double().reshape(-1).numpy()
+            assert g @ want_u / (np.linalg.norm(g) * np.linalg.norm(want_u)) >= 0.999999, names[int(j)]

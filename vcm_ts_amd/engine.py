@@ -103,6 +103,7 @@ class Engine:
         # dcvc_conv2d_k32 (16x16x32 MFMA, 32-channel chunks) for the stride-1 3x3 / 1x1 layers it covers; DCVC_K32=0
         # keeps them on dcvc_conv2d (developer A/B switch: an encoder and its decoder must use the same setting)
         self.use_k32 = os.environ.get("DCVC_K32", "1") != "0"
+        self.k32_everywhere = False  # tests: route every layer the kernel covers to it, whatever its size
         self.k32_sizes = tuple(int(k) for k in os.environ.get("DCVC_K32_SIZES", "3").split(","))  # kernel sizes it takes (1x1 layers are HBM-bound: conv_mfma's full-line stores are 10-15 % faster there)
         # fp16x3 mode clamps |activation| > 8188 on load; with range_check on, every convolution launch also
         # flags outputs beyond that magnitude in the status word (check_status() raises).  Off by default: it
@@ -393,14 +394,23 @@ class Engine:
         return q
 
     def k32_capable(self, pk: PackedConv, stride, out: View, res, res2, gate) -> bool:
-        """Layers dcvc_conv2d_k32 covers: fp16x3, 3x3 or 1x1, stride 1, every input segment a multiple of 32 channels,
-        16-byte-addressable epilogue (4-channel groups of out / residuals)."""
+        """Layers routed to dcvc_conv2d_k32: fp16x3, 3x3, stride 1, every input segment a multiple of 32 channels,
+        16-byte-addressable epilogue (4-channel groups of out / residuals) -- what the kernel covers -- and, from the
+        per-layer comparison inside a 1080p P picture (profiles/r03_k32_vs_conv_mfma_in_pipeline.txt), only where it
+        wins: output-channel blocks of 64 (its 32-column variant is 25-40 % slower than conv_mfma's) and at least
+        ~1000 workgroups (below that the two are within noise or conv_mfma is ahead).  Geometry only: an encoder and
+        its decoder take the same decision."""
         if not (self.precision == "fp16x3" and self.tape is None and self.use_k32 and getattr(pk, "host", False)):
             return False
         cfin = pk.Cout // 4 if pk.ps else pk.Cout
         al = lambda v: v is None or (v.ptr % 16 == 0 and v.cs % 4 == 0)
-        return (pk.ks in self.k32_sizes and stride == 1 and all(c % 32 == 0 for c in pk.seg_C) and cfin % 4 == 0
-                and al(out) and al(res) and al(res2) and (gate is None or gate.data_ptr() % 16 == 0))
+        covered = (pk.ks in self.k32_sizes and stride == 1 and all(c % 32 == 0 for c in pk.seg_C) and cfin % 4 == 0
+                   and al(out) and al(res) and al(res2) and (gate is None or gate.data_ptr() % 16 == 0))
+        if not covered or self.k32_everywhere:
+            return covered
+        m = 2 if pk.ps else 1
+        tiles = out.N * ((out.H // m + 7) // 8) * ((out.W // m + 31) // 32)
+        return pk.Cout_pad % 64 == 0 and tiles * (pk.Cout_pad // 64) >= 1000
 
     def small_capable(self, pk: PackedConv, stride, gate, res2, chan_partial) -> bool:
         """Layers dcvc_conv2d_small covers: <= 16 output channels, 3x3 / 7x7, stride 1, plain epilogue, fp16x3."""
