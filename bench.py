@@ -195,6 +195,38 @@ class GopQuality:
         return 10.0 * np.log10(1.0 / mse)
 
 
+def files_workload(args, dev, n_frames):
+    """the reference's file loop (video_coder.run_dcvc: PNG in, one .bin per picture out) around the same
+    encoder, reported SEPARATELY from `value`: PNG decode + host->device + encode + rANS + .bin write per picture, one
+    GOP stream, from a temporary folder of synthetic 8-bit PNGs (written untimed).  vcm_ts_amd/run_codec.py."""
+    import shutil
+    import tempfile
+    import time
+
+    from vcm_ts_amd.run_codec import encode_folder, save_torch_image
+
+    tmp = tempfile.mkdtemp(prefix="dcvc_files_")
+    try:
+        src, dst = os.path.join(tmp, "png"), os.path.join(tmp, "bin")
+        os.makedirs(src)
+        for t, f in enumerate(synth_sequence(dev, n_frames, args.height, args.width, 11)):
+            save_torch_image(f, os.path.join(src, f"im{str(t + 1).zfill(5)}.png"))
+        png_bytes = sum(os.path.getsize(os.path.join(src, n)) for n in os.listdir(src))
+        encode_folder(src, dst, None, args.gop, (1.0, 1.0, 1.0), str(dev), args.precision, max_frames=3)  # warm-up
+        shutil.rmtree(dst)
+        torch.cuda.synchronize(dev)
+        t0 = time.time()
+        bits, size = encode_folder(src, dst, None, args.gop, (1.0, 1.0, 1.0), str(dev), args.precision)
+        torch.cuda.synchronize(dev)
+        dt = time.time() - t0
+        return {"value": round(len(bits) / dt, 3), "unit": "frames/s", "frames": len(bits), "ms_per_frame": round(dt / len(bits) * 1e3, 2),
+                "png_mbytes_read": round(png_bytes / 1e6, 1), "bin_mbytes_written": round(sum(bits) / 8e6, 1),
+                "workload": f"run_codec encode of a folder of {len(bits)} synthetic {size[1]}x{size[0]} PNGs into .bin files (GOP "
+                            f"{args.gop}, one GOP stream, PNG decode and file writes inside the timed region); = bench.py --workload files"}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def train_workload(args, dev, rank, world):
     """BASELINE configs[2] (N=1) / configs[3] (N>1): a step is forward_one_frame + backward + AdamW on
     a batch of 4 256x256 pictures per GPU (`single` mode: one optimiser step per P picture,
@@ -302,8 +334,9 @@ def main():
     ap.add_argument("--gop-streams", type=int, default=2,
                     help="GOPs in flight per GPU (own codec instances and HIP stream each, one host thread); a step "
                          "codes this many GOPs")
-    ap.add_argument("--workload", default="encode", choices=["encode", "decode", "train"],
-                    help="encode: BASELINE configs[1] (the headline metric, default); decode: the same GOPs through "
+    ap.add_argument("--workload", default="encode", choices=["encode", "decode", "train", "files"],
+                    help="files: the PNG-folder -> .bin-folder loop of run_codec (file I/O inside the timed region); "
+                         "encode: BASELINE configs[1] (the headline metric, default); decode: the same GOPs through "
                          "decompress (payloads made once, untimed); train: configs[2]/[3], one optimiser step of "
                          "trainer.py / trainer_multi.py per bench step (batch 4 of 256x256 per GPU, DDP over RCCL)")
     ap.add_argument("--no-extra-workloads", action="store_true",
@@ -338,6 +371,15 @@ def main():
     dev = torch.device("cuda", local % torch.cuda.device_count())
     torch.cuda.set_device(dev)
 
+    if args.workload == "files":
+        if world != 1:
+            raise SystemExit("bench.py --workload files is a one-GPU measurement")
+        r = files_workload(args, dev, args.gop)
+        print(json.dumps({"metric": "encoded frames/sec at 1920x1080 GOP-32, PNG folder in, .bin folder out", "value": r["value"],
+                          "unit": "frames/s", "n_gpus": 1, "steps": 1, "warmup": 0, "ms_per_step": round(r["ms_per_frame"] * r["frames"], 2),
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                          "config": r}))
+        return
     if args.workload == "train":
         out = train_workload(args, dev, rank, world)
         if rank == 0:
@@ -538,6 +580,7 @@ def main():
                          "workload": f"decode of the same {K} GOPs (reference bitstream: 3 / 6 host rANS round trips per I / P "
                                      "picture), one host thread and HIP stream per GOP; = bench.py --workload decode"}
         del coded
+        out["files"] = files_workload(args, dev, 16)  # PNG -> .bin loop, I/O inside the timed region
         for e_ in cenc.encoders:  # free the 1080p workspaces before the training model allocates its own
             e_.i_net.engine().release()
             e_.p_net.engine().release()
