@@ -497,9 +497,18 @@ def test_build_indexes_bit_exact_against_reference_planes(eng):
         eb = scale_index_edges(dist)[:-1].view(torch.int32)
         near = torch.cat([(eb + d).view(torch.float32) for d in range(-3, 4)])
         rnd = torch.exp(torch.empty(4_000_000).uniform_(-13.0, 6.0, generator=g))
-        for t in (near, rnd):
-            np.testing.assert_array_equal(eng.scale_indexes(t.cuda(), dist).cpu().numpy(),
-                                          R.scale_indexes(t.clone(), dist).numpy())
+        edges = scale_index_edges(dist)
+        for t, what in ((near, "within 3 ulp of an edge"), (rnd, "random")):
+            got = eng.scale_indexes(t.cuda(), dist).cpu()
+            # the kernels count the CONSTANT edges (vcm_ts_amd/index_edges.py, derived where the reference fixtures were made)
+            assert torch.equal(got, torch.searchsorted(edges, t, right=True).int())
+            # the reference formula evaluated by THIS host's torch-CPU logf may sit one ulp off at an edge (round 3: the
+            # GPU box's CPU bins 15 of the 1785 near-edge floats differently from the build container's -- which is
+            # why the edges are constants now: two hosts that each derived their own would not decode each other)
+            host = R.scale_indexes(t.clone(), dist)
+            n_off = int((host != got).sum())
+            print(f"[{dist}] {what}: {n_off} of {t.numel()} binned differently by this host's logf")
+            assert n_off <= (0.02 * t.numel() if t is near else 8) and int((host - got).abs().max()) <= 1
 
 
 @pytest.mark.parametrize("dist,C", [("laplace", 64), ("gaussian", 192)])

@@ -408,8 +408,10 @@ class Engine:
                    and al(out) and al(res) and al(res2) and (gate is None or gate.data_ptr() % 16 == 0))
         if not covered or self.k32_everywhere:
             return covered
+        # per-IMAGE geometry, never the batch size: a batch of rate points is decoded one element at a time
+        # (test_config_c5_four_rate_points_at_bench_size caught a batch-dependent rule)
         m = 2 if pk.ps else 1
-        tiles = out.N * ((out.H // m + 7) // 8) * ((out.W // m + 31) // 32)
+        tiles = ((out.H // m + 7) // 8) * ((out.W // m + 31) // 32)
         return pk.Cout_pad % 64 == 0 and tiles * (pk.Cout_pad // 64) >= 1000
 
     def small_capable(self, pk: PackedConv, stride, gate, res2, chan_partial) -> bool:
