@@ -139,11 +139,18 @@ __global__ __launch_bounds__(256, 2) void conv_k32(const K32 a) {
         poff[u] = ok ? gy * a.W + gx : 0;
         inpic |= (ok ? 1u : 0u) << u;
     }
+    // Address arithmetic is kept off the vector ALU (round 3: SQ counters showed the VALU 40 % busy, a third of it 64-bit
+    // address math in the main loop): every global access is a wave-uniform base pointer (scalar registers) plus a 32-bit
+    // per-lane byte offset (tensors stay below 4 GiB), one v_mad_u32_u24 per load at most.
+    auto ld16 = [](const void *base, unsigned byte_off) __attribute__((always_inline)) {
+        return *(const f32x4 *)((const char *)base + byte_off);
+    };
     auto load_patch = [&](const Cursor &k) {
-        const int cs = a.seg_cs[k.s];
-        const float *sp = a.seg_ptr[k.s] + (size_t)img * a.H * a.W * cs + k.c0 + (tid & 7) * 4;
+        const unsigned cs4 = (unsigned)a.seg_cs[k.s] * 4u;  // bytes per pixel of this segment (< 2^24)
+        const char *sp = (const char *)(a.seg_ptr[k.s] + (size_t)img * a.H * a.W * a.seg_cs[k.s] + k.c0);
+        const unsigned lane_off = (tid & 7) * 16u;
 #pragma unroll
-        for (int u = 0; u < NP; ++u) rp[u] = *(const f32x4 *)(sp + (size_t)poff[u] * cs);
+        for (int u = 0; u < NP; ++u) rp[u] = ld16(sp, __umul24((unsigned)poff[u], cs4) + lane_off);
     };
     auto store_patch = [&]() {
 #pragma unroll
@@ -168,14 +175,18 @@ __global__ __launch_bounds__(256, 2) void conv_k32(const K32 a) {
             }
         }
     };
-    auto load_w = [&](const Cursor &k) {
-        const float *wsrc = a.wpack + ((size_t)(k.cg * T + k.st * TPS) * 8) * a.Cout_pad * 4 + (size_t)n0 * 4;
+    unsigned wofs[NW];  // this thread's float4s of a filter row: byte offsets, the same for every step
 #pragma unroll
-        for (int u = 0; u < NW; ++u) {
-            const int i = tid + u * 256;
-            const int row = i / BN, col = i - row * BN;
-            if (i < TPS * 8 * BN) rw[u] = *(const f32x4 *)(wsrc + ((size_t)row * a.Cout_pad + col) * 4);
-        }
+    for (int u = 0; u < NW; ++u) {
+        const int i = tid + u * 256;
+        const int row = i / BN, col = i - row * BN;
+        wofs[u] = i < TPS * 8 * BN ? (unsigned)(row * a.Cout_pad + col) * 16u : 0u;
+    }
+    auto load_w = [&](const Cursor &k) {
+        const char *wsrc = (const char *)(a.wpack + ((size_t)(k.cg * T + k.st * TPS) * 8) * a.Cout_pad * 4 + (size_t)n0 * 4);
+#pragma unroll
+        for (int u = 0; u < NW; ++u)
+            if (u + 1 < NW || tid + u * 256 < TPS * 8 * BN) rw[u] = ld16(wsrc, wofs[u]);
     };
     auto store_w = [&]() {
 #pragma unroll
@@ -270,25 +281,37 @@ __global__ __launch_bounds__(256, 2) void conv_k32(const K32 a) {
         for (int n = 0; n < NTW; ++n)
             if (oy[m] < a.H && ox[m] < a.W && n0 + n * 16 + (lane >> 4) * 4 < a.Cout) okm |= 1u << (m * NTW + n);
     }
-    // element offset of (pixel m, channel quad starting at ch) in a tensor laid out like the output
-    auto out_off = [&](int m, int ch, int cs) __attribute__((always_inline)) -> size_t {
-        if (!a.ps) return ((size_t)(img * a.H + oy[m]) * a.W + ox[m]) * cs + ch;
-        const int sub = ch / Cq, cf = ch - sub * Cq;  // (Cq % 4 == 0: a quad stays inside one sub-pixel plane)
-        return ((size_t)(img * Ho + 2 * oy[m] + (sub >> 1)) * Wo + 2 * ox[m] + (sub & 1)) * cs + cf;
-    };
-    f32x4 rv[4][NTW];
-    auto load_res = [&](int m) __attribute__((always_inline)) {
+    // byte offset of (pixel m, channel quad n) in a tensor laid out like the output, from the image's base
+    // (32-bit: an image of a tensor stays below 4 GiB)
+    unsigned pixo[4];  // pixel index inside the (pixel-shuffled) output image (< 2^24)
 #pragma unroll
-        for (int n = 0; n < NTW; ++n) {
-            const bool ok = (okm >> (m * NTW + n)) & 1u;
-            rv[m][n] = *(const f32x4 *)&a.res[ok ? out_off(m, n0 + n * 16 + (lane >> 4) * 4, a.res_cs) : 0];
-        }
+    for (int m = 0; m < 4; ++m) pixo[m] = a.ps ? (unsigned)((2 * oy[m]) * Wo + 2 * ox[m]) : (unsigned)(oy[m] * a.W + ox[m]);
+    unsigned chq[NTW], pso[NTW];  // per channel quad: channel inside its (sub-pixel) plane, pixel offset of that plane
+#pragma unroll
+    for (int n = 0; n < NTW; ++n) {
+        const int ch = n0 + n * 16 + (lane >> 4) * 4;
+        const int sub = a.ps ? ch / Cq : 0;  // (Cq % 4 == 0: a quad stays inside one sub-pixel plane)
+        chq[n] = (unsigned)(ch - sub * Cq);
+        pso[n] = (unsigned)((sub >> 1) * Wo + (sub & 1));
+    }
+    // (24-bit multiplies: full-rate VALU; v_mul_lo_u32 is quarter rate)
+    auto out_off = [&](int m, int n, int cs) __attribute__((always_inline)) -> unsigned {
+        return (__umul24(pixo[m] + pso[n], (unsigned)cs) + chq[n]) * 4u;
     };
+    const size_t img_pix = (size_t)img * Ho * Wo;  // (uniform)
+    const char *res_b = a.res ? (const char *)(a.res + img_pix * a.res_cs) : nullptr;
+    const char *res2_b = a.res2 ? (const char *)(a.res2 + img_pix * a.res2_cs) : nullptr;
+    char *out_b = (char *)(a.out + img_pix * a.out_cs);
+    f32x4 rv[4][NTW];
     K32_STAMP(57);
     K32_STAMP(58);
-    if (a.res) {
+    if (a.res) {  // (requesting these under the last step's MFMAs was tried: the compiler then keeps 64 registers for them
+                  // across the whole loop and spills)
 #pragma unroll
-        for (int m = 0; m < 4; ++m) load_res(m);
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int n = 0; n < NTW; ++n)
+                rv[m][n] = ld16(res_b, ((okm >> (m * NTW + n)) & 1u) ? out_off(m, n, a.res_cs) : 0u);
     }
     f32x4 csum[NTW];
     float vmax = 0.f;  // largest |output| this lane stores (range guard)
@@ -320,12 +343,12 @@ __global__ __launch_bounds__(256, 2) void conv_k32(const K32 a) {
                 }
             }
             if ((okm >> (m * NTW + n)) & 1u) {
-                if (a.res2) v = *(const f32x4 *)&a.res2[out_off(m, ch, a.res2_cs)] + v;
+                if (a.res2) v = ld16(res2_b, out_off(m, n, a.res2_cs)) + v;
                 if (a.chan_partial) csum[n] += v;
                 // range guard, always on (two v_max3_f32 per 4 outputs): an output beyond +-8188 would be clamped by
                 // a split-fp16 consumer.  An infinity is caught here; a NaN can only follow one.
                 vmax = fmaxf(vmax, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
-                *(f32x4 *)&a.out[out_off(m, ch, a.out_cs)] = v;
+                *(f32x4 *)(out_b + out_off(m, n, a.out_cs)) = v;
             }
         }
     }
