@@ -42,6 +42,11 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 #ifndef K32_STAMP
 #define K32_STAMP(i)
 #endif
+// developer ablation builds (tools/build_variant.sh ... -DK32_ABLATE=n): 1 = no MFMAs (fragment reads kept alive),
+// 2 = no fragment reads and no MFMAs, 4 = no epilogue stores / residual loads.  0 in the product.
+#ifndef K32_ABLATE
+#define K32_ABLATE 0
+#endif
 
 namespace {
 
@@ -81,13 +86,16 @@ struct K32 {
 
 __device__ __forceinline__ float act(float v, float slope) { return v > 0.f ? v : v * slope; }
 
-template <int KS, int NTW>
-__global__ __launch_bounds__(256, 2) void conv_k32(const K32 a) {
+template <int KS, int NTW, int NWAVE>
+__global__ __launch_bounds__(64 * NWAVE, NWAVE / 2) void conv_k32(const K32 a) {
+    // NWAVE waves per workgroup (4 or 8): wave w owns RW = 8 / NWAVE rows of the tile, i.e. MT = 2 * RW M tiles.  With 8
+    // waves two resident workgroups put FOUR waves on every SIMD (128 registers each) instead of two
+    constexpr int NTH = 64 * NWAVE, RW = 8 / NWAVE, MT = 2 * RW;
     constexpr int BH = 8, BW = 32, BN = 16 * NTW;
     constexpr int PH = BH + KS - 1, PW = BW + KS - 1, PAD = KS / 2;
     constexpr int T = KS * KS, TPS = KS, NST = KS;  // one filter row of taps in LDS at a time
     constexpr int LDS_MAIN = PH * PW * REC + TPS * 8 * BN * 4;
-    static_assert(LDS_MAIN >= 4 * BN, "the SE reduction reuses the front of the buffer");
+    static_assert(LDS_MAIN >= NWAVE * BN, "the SE reduction reuses the front of the buffer");
     __shared__ __attribute__((aligned(16))) float lds[LDS_MAIN];
     float *patch = lds;
     float *wl = lds + PH * PW * REC;
@@ -98,20 +106,20 @@ __global__ __launch_bounds__(256, 2) void conv_k32(const K32 a) {
     const int ty = blockIdx.y + a.ty0;
     const int x0 = tx * BW, y0 = ty * BH, n0 = nb * BN, img = blockIdx.z;
 
-    f32x4 acc[4][NTW];
+    f32x4 acc[MT][NTW];
 #pragma unroll
-    for (int m = 0; m < 4; ++m)
+    for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int n = 0; n < NTW; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    // M tile m of a wave: row 2 * wave + (m >> 1), pixels 16 * (m & 1) .. + 15
-    const int a_base = ((wave * 2) * PW + (lane & 15)) * REC + (lane >> 4) * 4;
+    // M tile m of a wave: row RW * wave + (m >> 1), pixels 16 * (m & 1) .. + 15
+    const int a_base = ((wave * RW) * PW + (lane & 15)) * REC + (lane >> 4) * 4;
     const int b_base = ((lane >> 4) * BN + (lane & 15)) * 4;
 
     // ---- software-pipelined main loop: a step is (32-channel chunk, filter row).  While the MFMAs of step k run,
     // the global loads of step k+1 are in flight into registers (rp: the patch, only when the chunk changes; rw: the
     // filter row) and are written to LDS after the barrier that ends step k.
-    constexpr int NP = (PH * PW * 8 + 255) / 256, NW = (TPS * 8 * BN + 255) / 256;
+    constexpr int NP = (PH * PW * 8 + NTH - 1) / NTH, NW = (TPS * 8 * BN + NTH - 1) / NTH;
     f32x4 rp[NP], rw[NW];
     struct Cursor {
         int s, c0, cg, st;
@@ -131,7 +139,7 @@ __global__ __launch_bounds__(256, 2) void conv_k32(const K32 a) {
     unsigned inpic = 0;
 #pragma unroll
     for (int u = 0; u < NP; ++u) {
-        const int i = tid + u * 256;
+        const int i = tid + u * NTH;
         const int p = i >> 3;
         const int py = p / PW, px = p - py * PW;
         const int gy = y0 - PAD + py, gx = x0 - PAD + px;
@@ -155,7 +163,7 @@ __global__ __launch_bounds__(256, 2) void conv_k32(const K32 a) {
     auto store_patch = [&]() {
 #pragma unroll
         for (int u = 0; u < NP; ++u) {
-            const int i = tid + u * 256;
+            const int i = tid + u * NTH;
             if (i < PH * PW * 8) {
                 f32x4 v = ((inpic >> u) & 1u) ? rp[u] : (f32x4){0.f, 0.f, 0.f, 0.f};
                 if (a.in_act) {
@@ -178,7 +186,7 @@ __global__ __launch_bounds__(256, 2) void conv_k32(const K32 a) {
     unsigned wofs[NW];  // this thread's float4s of a filter row: byte offsets, the same for every step
 #pragma unroll
     for (int u = 0; u < NW; ++u) {
-        const int i = tid + u * 256;
+        const int i = tid + u * NTH;
         const int row = i / BN, col = i - row * BN;
         wofs[u] = i < TPS * 8 * BN ? (unsigned)(row * a.Cout_pad + col) * 16u : 0u;
     }
@@ -186,23 +194,24 @@ __global__ __launch_bounds__(256, 2) void conv_k32(const K32 a) {
         const char *wsrc = (const char *)(a.wpack + ((size_t)(k.cg * T + k.st * TPS) * 8) * a.Cout_pad * 4 + (size_t)n0 * 4);
 #pragma unroll
         for (int u = 0; u < NW; ++u)
-            if (u + 1 < NW || tid + u * 256 < TPS * 8 * BN) rw[u] = ld16(wsrc, wofs[u]);
+            if (u + 1 < NW || tid + u * NTH < TPS * 8 * BN) rw[u] = ld16(wsrc, wofs[u]);
     };
     auto store_w = [&]() {
 #pragma unroll
         for (int u = 0; u < NW; ++u) {
-            const int i = tid + u * 256;
+            const int i = tid + u * NTH;
             if (i < TPS * 8 * BN) *(f32x4 *)&wl[i * 4] = rw[u];
         }
     };
 
     auto mfma_step = [&](int st) __attribute__((always_inline)) {
+        if (K32_ABLATE & 2) return;
         const int a_st = st * PW * REC;  // filter row ky = st
 #pragma unroll
         for (int tl = 0; tl < TPS; ++tl) {  // kx = tl
-            f16x8 ah[4], al[4], bh[NTW], bl[NTW];
+            f16x8 ah[MT], al[MT], bh[NTW], bl[NTW];
 #pragma unroll
-            for (int m = 0; m < 4; ++m) {
+            for (int m = 0; m < MT; ++m) {
                 const float *rec = &patch[a_base + a_st + ((m >> 1) * PW + (m & 1) * 16 + tl) * REC];
                 ah[m] = *(const f16x8 *)rec;
                 al[m] = *(const f16x8 *)(rec + 16);
@@ -212,8 +221,15 @@ __global__ __launch_bounds__(256, 2) void conv_k32(const K32 a) {
                 bh[n] = *(const f16x8 *)&wl[b_base + ((tl * 2 + 0) * 4 * BN + n * 16) * 4];
                 bl[n] = *(const f16x8 *)&wl[b_base + ((tl * 2 + 1) * 4 * BN + n * 16) * 4];
             }
+            if (K32_ABLATE & 1) {  // keep the fragment reads, drop the matrix work
 #pragma unroll
-            for (int m = 0; m < 4; ++m)
+                for (int m = 0; m < MT; ++m) asm volatile("" ::"v"(ah[m]), "v"(al[m]));
+#pragma unroll
+                for (int n = 0; n < NTW; ++n) asm volatile("" ::"v"(bh[n]), "v"(bl[n]));
+                continue;
+            }
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
 #pragma unroll
                 for (int n = 0; n < NTW; ++n) {
                     // filter as the A operand, pixels as B: D[channel][pixel], i.e. a lane ends up with 4 CONSECUTIVE
@@ -271,11 +287,11 @@ __global__ __launch_bounds__(256, 2) void conv_k32(const K32 a) {
     const int Cfin = a.ps ? Cq : a.Cout;
     const int Ho = a.ps ? a.H * 2 : a.H, Wo = a.ps ? a.W * 2 : a.W;
     constexpr float inv_scale = 1.f / (ACT_SCALE * WGT_SCALE);
-    int oy[4], ox[4];
+    int oy[MT], ox[MT];
     unsigned okm = 0;  // bit m * NTW + n
 #pragma unroll
-    for (int m = 0; m < 4; ++m) {
-        oy[m] = y0 + wave * 2 + (m >> 1);
+    for (int m = 0; m < MT; ++m) {
+        oy[m] = y0 + wave * RW + (m >> 1);
         ox[m] = x0 + (m & 1) * 16 + (lane & 15);
 #pragma unroll
         for (int n = 0; n < NTW; ++n)
@@ -283,9 +299,9 @@ __global__ __launch_bounds__(256, 2) void conv_k32(const K32 a) {
     }
     // byte offset of (pixel m, channel quad n) in a tensor laid out like the output, from the image's base
     // (32-bit: an image of a tensor stays below 4 GiB)
-    unsigned pixo[4];  // pixel index inside the (pixel-shuffled) output image (< 2^24)
+    unsigned pixo[MT];  // pixel index inside the (pixel-shuffled) output image (< 2^24)
 #pragma unroll
-    for (int m = 0; m < 4; ++m) pixo[m] = a.ps ? (unsigned)((2 * oy[m]) * Wo + 2 * ox[m]) : (unsigned)(oy[m] * a.W + ox[m]);
+    for (int m = 0; m < MT; ++m) pixo[m] = a.ps ? (unsigned)((2 * oy[m]) * Wo + 2 * ox[m]) : (unsigned)(oy[m] * a.W + ox[m]);
     unsigned chq[NTW], pso[NTW];  // per channel quad: channel inside its (sub-pixel) plane, pixel offset of that plane
 #pragma unroll
     for (int n = 0; n < NTW; ++n) {
@@ -302,13 +318,13 @@ __global__ __launch_bounds__(256, 2) void conv_k32(const K32 a) {
     const char *res_b = a.res ? (const char *)(a.res + img_pix * a.res_cs) : nullptr;
     const char *res2_b = a.res2 ? (const char *)(a.res2 + img_pix * a.res2_cs) : nullptr;
     char *out_b = (char *)(a.out + img_pix * a.out_cs);
-    f32x4 rv[4][NTW];
+    f32x4 rv[MT][NTW];
     K32_STAMP(57);
     K32_STAMP(58);
     if (a.res) {  // (requesting these under the last step's MFMAs was tried: the compiler then keeps 64 registers for them
                   // across the whole loop and spills)
 #pragma unroll
-        for (int m = 0; m < 4; ++m)
+        for (int m = 0; m < MT; ++m)
 #pragma unroll
             for (int n = 0; n < NTW; ++n)
                 rv[m][n] = ld16(res_b, ((okm >> (m * NTW + n)) & 1u) ? out_off(m, n, a.res_cs) : 0u);
@@ -323,7 +339,7 @@ __global__ __launch_bounds__(256, 2) void conv_k32(const K32 a) {
         f32x4 gate = {1.f, 1.f, 1.f, 1.f};
         if (a.res_gate && ch < a.Cout) gate = *(const f32x4 *)&a.res_gate[(size_t)img * Cfin + (a.ps ? ch % Cq : ch)];
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
+        for (int m = 0; m < MT; ++m) {
             f32x4 v = acc[m][n] * inv_scale + bias;
             if (a.out_act == 1) {
                 v[0] = act(v[0], a.out_slope);
@@ -348,7 +364,8 @@ __global__ __launch_bounds__(256, 2) void conv_k32(const K32 a) {
                 // range guard, always on (two v_max3_f32 per 4 outputs): an output beyond +-8188 would be clamped by
                 // a split-fp16 consumer.  An infinity is caught here; a NaN can only follow one.
                 vmax = fmaxf(vmax, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
-                *(f32x4 *)(out_b + out_off(m, n, a.out_cs)) = v;
+                if (!(K32_ABLATE & 4)) *(f32x4 *)(out_b + out_off(m, n, a.out_cs)) = v;
+                else asm volatile("" ::"v"(v));
             }
         }
     }
@@ -372,14 +389,16 @@ __global__ __launch_bounds__(256, 2) void conv_k32(const K32 a) {
             for (int n = 0; n < NTW; ++n) *(f32x4 *)&red[wave * BN + n * 16 + (lane >> 4) * 4] = csum[n];
         __syncthreads();
         if (tid < BN && n0 + tid < a.Cout_pad) {
-            const float s = ((red[tid] + red[BN + tid]) + red[2 * BN + tid]) + red[3 * BN + tid];
+            float s = red[tid];
+#pragma unroll
+            for (int w = 1; w < NWAVE; ++w) s += red[w * BN + tid];  // fixed order
             const size_t part = (size_t)img * (a.nty * a.ntx) + (size_t)ty * a.ntx + tx;
             a.chan_partial[part * a.Cout_pad + n0 + tid] = s;
         }
     }
 }
 
-template <int KS, int NTW>
+template <int KS, int NTW, int NWAVE>
 int launch(K32 &k, int N, hipStream_t st) {
     constexpr int BN = 16 * NTW;
     k.ntx = (k.W + 31) / 32;
@@ -387,7 +406,7 @@ int launch(K32 &k, int N, hipStream_t st) {
     if (k.ty0 < 0 || k.ty0 >= k.nty) return DCVC_E_ARG;
     const int rows = k.band_rows > 0 ? (k.band_rows < k.nty - k.ty0 ? k.band_rows : k.nty - k.ty0) : k.nty;
     dim3 grid((unsigned)(k.ntx * (k.Cout_pad / BN)), (unsigned)rows, (unsigned)N);
-    hipLaunchKernelGGL((conv_k32<KS, NTW>), grid, dim3(256), 0, st, k);
+    hipLaunchKernelGGL((conv_k32<KS, NTW, NWAVE>), grid, dim3(64 * NWAVE), 0, st, k);
     return hipGetLastError() == hipSuccess ? DCVC_OK : DCVC_E_LAUNCH;
 }
 
@@ -490,6 +509,10 @@ extern "C" int dcvc_conv2d_k32(const dcvc_conv_args *a, void *stream) {
     if (a->chan_partial && a->pixel_shuffle) return DCVC_E_ARG;
     hipStream_t st = (hipStream_t)stream;
     const bool wide = (a->Cout_pad % 64) == 0;
-    if (a->ks == 3) return wide ? launch<3, 4>(k, a->N, st) : launch<3, 2>(k, a->N, st);
-    return wide ? launch<1, 4>(k, a->N, st) : launch<1, 2>(k, a->N, st);
+    // the wide 3x3 kernel runs as 8-wave workgroups (four waves per SIMD with two resident workgroups); DCVC_K32_WAVES=4
+    // is the developer A/B switch back to 4 waves (same results either way; read per call)
+    const char *env = getenv("DCVC_K32_WAVES");
+    const bool w8 = !(env && atoi(env) == 4);
+    if (a->ks == 3) return wide ? (w8 ? launch<3, 4, 8>(k, a->N, st) : launch<3, 4, 4>(k, a->N, st)) : launch<3, 2, 4>(k, a->N, st);
+    return wide ? launch<1, 4, 4>(k, a->N, st) : launch<1, 2, 4>(k, a->N, st);
 }
