@@ -451,19 +451,19 @@ def main():
     bits = bits / K  # per GOP
     frames_total = K * args.gop * args.steps * world
     fps = frames_total / dt
-    # the same GOP alone on the GPU (one stream), untimed for `value`: first plainly (the one-stream rate), then once
-    # more as a CHECKED pass: per-picture PSNR of this mode's reconstructions and every convolution output tested
-    # against the magnitude the split-fp16 operands can hold (conv_k32's guard is always on; this adds the others)
+    # the same GOP alone on the GPU (one stream), untimed for `value`: the one-stream rate, then once more with the
+    # reconstructions' PSNR collected.  The range guard of the fast mode (every convolution output against the
+    # magnitude split-fp16 operands can hold) is on in every launch of this program, the timed ones included
     eng_i, eng_p = i_net.engine(), p_net.engine()
+    assert eng_i.range_check and eng_p.range_check
     dt1, bits1 = timed_region(lambda: enc.encode_gop(seq, q_i, q_mv, q_y)[1], dev)
     one_stream = round(args.gop / dt1, 3)
-    saturation = eng_i.read_status() | eng_p.read_status()  # what the always-on guard saw during the timed steps
-    eng_i.range_check = eng_p.range_check = True
     quality = GopQuality(seq, args.height, args.width)
-    bits1_checked = enc.encode_gop(seq, q_i, q_mv, q_y, on_recon=quality)[1]
-    assert bits1_checked == bits1, "the checked pass codes the same bytes"
-    saturation |= eng_i.read_status() | eng_p.read_status()
-    eng_i.range_check = eng_p.range_check = False
+    bits1_again = enc.encode_gop(seq, q_i, q_mv, q_y, on_recon=quality)[1]
+    assert bits1_again == bits1, "the same GOP codes the same bytes"
+    saturation = eng_i.read_status() | eng_p.read_status()
+    for e_ in cenc.encoders:
+        saturation |= e_.i_net.engine().read_status() | e_.p_net.engine().read_status()
     psnr_fast = quality.psnr()
 
     # ---- roofline of the dominant kernel, measured live with HIP events on the launch stream
@@ -538,8 +538,9 @@ def main():
                    "psnr_db_gop_mean": round(float(psnr_fast.mean()), 4),
                    "psnr_note": "random-init weights: PSNR is a parity quantity here, not codec quality",
                    "fp16x3_range_status": int(saturation),
-                   "fp16x3_range_note": "0 = no convolution output of the checked GOP exceeded |8188|, the magnitude split-fp16 "
-                                        "operands can hold (DCVC_STATUS_ACT_SATURATED otherwise)"},
+                   "fp16x3_range_note": "0 = no convolution output of ANY launch of this run (timed steps included: the guard is "
+                                        "always on) exceeded |8188|, the magnitude split-fp16 operands can hold "
+                                        "(DCVC_STATUS_ACT_SATURATED otherwise)"},
         "roofline": roofline,
     }
     parity_ok = True

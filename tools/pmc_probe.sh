@@ -35,7 +35,7 @@ for db in sorted(glob.glob("gpurun_out/pmc_tmp/*_results.db")):
     except Exception as e:
         out.write(f"# {db}: {e}\n"); continue
     for n, cn, k, a, d in rows:
-        short = "conv_k32<3,4>" if "conv_k32" in n else ("conv_mfma<3,1,2,2,true>" if "conv_mfma" in n else n[:30])
+        short = "conv_k32<3,4,8>" if "conv_k32" in n else ("conv_mfma<3,1,2,2,true>" if "conv_mfma" in n else n[:30])
         out.write(f"{cn:40s} {short:26s} records {k:6d}  avg {a:18.1f}   avg duration {d/1e3:8.1f} us\n")
 out.close()
 print(open(f"gpurun_out/{sys.argv[1]}.txt").read())

@@ -13,7 +13,7 @@ for db in sorted(glob.glob("gpurun_out/sq_tmp/*_results.db")):
     c = sqlite3.connect(db)
     rows = c.execute("select name, counter_name, count(*), avg(counter_value) from pmc_events where name like '%conv_%' group by name, counter_name order by name, counter_name").fetchall()
     for n, cn, k, a in rows:
-        short = "conv_k32<3,4>" if "conv_k32" in n else ("conv_mfma<3,1,2,2,true>" if "conv_mfma" in n else n[:30])
+        short = "conv_k32<3,4,8>" if "conv_k32" in n else ("conv_mfma<3,1,2,2,true>" if "conv_mfma" in n else n[:30])
         print(f"{short:26s} {cn:28s} records {k:6d} avg {a:16.1f}")
 PY
 rm -rf $OUT

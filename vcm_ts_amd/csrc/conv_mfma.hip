@@ -288,7 +288,8 @@ __global__ __launch_bounds__(256, 2) void conv_mfma(const ConvK a) {
     const int Cfin = a.ps ? Cq : a.Cout;
     const int Ho = a.ps ? a.Hout * 2 : a.Hout, Wo = a.ps ? a.Wout * 2 : a.Wout;
     const float inv_scale = SPLIT ? 1.f / (ACT_SCALE * WGT_SCALE) : 1.f;
-    bool sat = false;
+    float vmax = 0.f;  // largest |output| this lane stores: the range guard (two v_max3_f32 per four outputs; an infinity is
+                       // caught, a NaN can only follow one)
     if (a.vec_epi) {
         // Vector path: the MFMA leaves a channel per lane and pixels in registers; a per-wave
         // transpose through LDS turns that into 4 consecutive channels per lane, so every
@@ -367,12 +368,12 @@ __global__ __launch_bounds__(256, 2) void conv_mfma(const ConvK a) {
                 if (a.res2) v = rv2[m][it] + v;
                 if (a.chan_partial && ok[m][it]) csum += v;
                 if (a.status && ok[m][it])
-                    sat |= !(fabsf(v[0]) <= ACT_LIMIT && fabsf(v[1]) <= ACT_LIMIT && fabsf(v[2]) <= ACT_LIMIT && fabsf(v[3]) <= ACT_LIMIT);
+                    vmax = fmaxf(vmax, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
                 if (ok[m][it]) *(f32x4 *)&a.out[pix[m][it] * a.out_cs + cf] = v;
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // reads done before the tile is rewritten
         }
-        if (sat) atomicOr(a.status, DCVC_STATUS_ACT_SATURATED);
+        if (a.status && !(vmax <= ACT_LIMIT)) atomicOr(a.status, DCVC_STATUS_ACT_SATURATED);
         if (a.chan_partial) {
             // SELayer's AdaptiveAvgPool (video_net.py:149-162) rides on the producing convolution: lanes with the
             // same channel quad are LPP apart -> butterfly inside the wave, the four waves through LDS, one
@@ -431,12 +432,12 @@ __global__ __launch_bounds__(256, 2) void conv_mfma(const ConvK a) {
                                         : ((size_t)(img * Ho + oy) * Wo + ox);
                 if (a.res) v = a.res_gate ? __builtin_fmaf(rv[r], gate, v) : v + rv[r];
                 if (a.res2) v = rv2[r] + v;
-                if (a.status && !(fabsf(v) <= ACT_LIMIT)) sat = true;
+                if (a.status) vmax = fmaxf(vmax, fabsf(v));
                 a.out[pix * a.out_cs + cf] = v;
             }
         }
     }
-    if (sat) atomicOr(a.status, DCVC_STATUS_ACT_SATURATED);
+    if (a.status && !(vmax <= ACT_LIMIT)) atomicOr(a.status, DCVC_STATUS_ACT_SATURATED);
 }
 
 

@@ -115,6 +115,7 @@ class Tape:
     def backward(self):
         e = self.e
         saved, e.tape = e.tape, None  # the gradient launches themselves are not recorded
+        guard, e.guard_outputs = e.guard_outputs, False  # the data-gradient launches reuse the forward kernel on gradients
         try:
             for op in reversed(self.ops):
                 getattr(self, "_b_" + op[0])(*op[1:])
@@ -124,6 +125,7 @@ class Tape:
                 torch.cuda.current_stream(e.device).wait_stream(e._wgrad_stream)
         finally:
             e.tape = saved
+            e.guard_outputs = guard
 
     # -- convolution ----------------------------------------------------------------------
     def _b_conv(self, pk, srcs, out, stride, in_slope, out_slope, res, gate, res2):
