@@ -65,3 +65,35 @@ def test_rate_point_selection_matches_reference_interpolation():
     assert rate_point_q_scales(i_q, y_q, mv_q, 6, 0) == (1.8, 12.0, 2.7)
     with pytest.raises(ValueError):
         rate_point_q_scales(i_q, y_q, mv_q, 6, 6)
+
+
+def test_prefetching_png_reader_returns_the_frames_of_the_sequential_reader(tmp_path):
+    """run_codec.PNGReader.prefetching (worker threads decoding ahead) yields the same arrays in the same order as
+    read_one_frame (DCVC_HEM/src/utils/png_reader.py:10-46: imNNNNN.png, RGB float32 / 255), for both naming widths,
+    and stops at the first missing index."""
+    from PIL import Image
+
+    import torch
+
+    from vcm_ts_amd.run_codec import PNGReader, u8_to_unit_float
+
+    rng = np.random.default_rng(5)
+    for width, n in ((5, 7), (1, 3)):
+        d = tmp_path / f"w{width}"
+        d.mkdir()
+        for t in range(n):
+            Image.fromarray(rng.integers(0, 256, (20, 36, 3), dtype=np.uint8)).save(d / f"im{str(t + 1).zfill(width)}.png")
+        Image.fromarray(np.zeros((20, 36, 3), np.uint8)).save(d / f"im{str(n + 2).zfill(width)}.png")  # after a gap: never read
+        seq, r = [], PNGReader(str(d))
+        while (f := r.read_one_frame()) is not None:
+            seq.append(f)
+        pre = list(PNGReader(str(d)).prefetching(workers=3, depth=4))
+        raw = list(PNGReader(str(d)).prefetching(workers=3, depth=4, raw=True))
+        assert len(seq) == len(pre) == len(raw) == n
+        for a, b, u in zip(seq, pre, raw):
+            assert a.dtype == np.float32 and a.shape == (3, 20, 36)
+            np.testing.assert_array_equal(a, b)
+            # the uint8 route (4x fewer bytes to the device, table look-up there) gives the same floats, bit for bit
+            np.testing.assert_array_equal(a, u8_to_unit_float(torch.from_numpy(u)).numpy()[0])
+    every = np.arange(256, dtype=np.uint8).reshape(16, 16, 1).repeat(3, axis=2)
+    np.testing.assert_array_equal(u8_to_unit_float(torch.from_numpy(every)).numpy()[0], every.astype("float32").transpose(2, 0, 1) / 255.0)
