@@ -91,6 +91,7 @@ __global__ __launch_bounds__(64 * NWAVE, NWAVE / 2) void conv_k32(const K32 a) {
     // NWAVE waves per workgroup (4 or 8): wave w owns RW = 8 / NWAVE rows of the tile, i.e. MT = 2 * RW M tiles.  With 8
     // waves two resident workgroups put FOUR waves on every SIMD (128 registers each) instead of two
     constexpr int NTH = 64 * NWAVE, RW = 8 / NWAVE, MT = 2 * RW;
+
     constexpr int BH = 8, BW = 32, BN = 16 * NTW;
     constexpr int PH = BH + KS - 1, PW = BW + KS - 1, PAD = KS / 2;
     constexpr int T = KS * KS, TPS = KS, NST = KS;  // one filter row of taps in LDS at a time
@@ -135,30 +136,36 @@ __global__ __launch_bounds__(64 * NWAVE, NWAVE / 2) void conv_k32(const K32 a) {
             }
         }
     };
-    int poff[NP];
-    unsigned inpic = 0;
-#pragma unroll
-    for (int u = 0; u < NP; ++u) {
-        const int i = tid + u * NTH;
-        const int p = i >> 3;
-        const int py = p / PW, px = p - py * PW;
-        const int gy = y0 - PAD + py, gx = x0 - PAD + px;
-        const bool ok = i < PH * PW * 8 && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-        poff[u] = ok ? gy * a.W + gx : 0;
-        inpic |= (ok ? 1u : 0u) << u;
-    }
-    // Address arithmetic is kept off the vector ALU (round 3: SQ counters showed the VALU 40 % busy, a third of it 64-bit
-    // address math in the main loop): every global access is a wave-uniform base pointer (scalar registers) plus a 32-bit
-    // per-lane byte offset (tensors stay below 4 GiB), one v_mad_u32_u24 per load at most.
+    // Nothing about a lane's staging slots is kept in registers across the loop (round 3: the 8-wave build had no room for
+    // the 6 pixel offsets + 3 filter offsets and spilled two of them to scratch, whose reloads -- vector-memory loads
+    // with a vmcnt(0) each -- sat in front of every chunk's patch request): a slot's patch pixel and its filter offset
+    // are recomputed where they are used, a dozen VALU operations per 16-byte load.
+    // Address arithmetic is kept off the 64-bit vector ALU: every global access is a wave-uniform base pointer (scalar
+    // registers) plus a 32-bit per-lane byte offset (tensors stay below 4 GiB).
+    static_assert(PH * PW * 241 < (1 << 23) && PW == 34 || KS != 3, "the multiply-shift below divides by PW = 34");
     auto ld16 = [](const void *base, unsigned byte_off) __attribute__((always_inline)) {
         return *(const f32x4 *)((const char *)base + byte_off);
     };
+    unsigned inpic = 0;  // bit u: slot u of the patch in the staging registers lies inside the picture
     auto load_patch = [&](const Cursor &k) {
         const unsigned cs4 = (unsigned)a.seg_cs[k.s] * 4u;  // bytes per pixel of this segment (< 2^24)
         const char *sp = (const char *)(a.seg_ptr[k.s] + (size_t)img * a.H * a.W * a.seg_cs[k.s] + k.c0);
-        const unsigned lane_off = (tid & 7) * 16u;
+        int t = tid;
+        asm volatile("" : "+v"(t));  // (opaque: keeps the compiler from hoisting the slot arithmetic back out of the loop)
+        const unsigned lane_off = (t & 7) * 16u;
+        inpic = 0;
 #pragma unroll
-        for (int u = 0; u < NP; ++u) rp[u] = ld16(sp, __umul24((unsigned)poff[u], cs4) + lane_off);
+        for (int u = 0; u < NP; ++u) {
+            const int i = t + u * NTH;
+            const int p = i >> 3;
+            const int py = PW == 34 ? (p * 241) >> 13 : p / PW, px = p - py * PW;
+            const int gy = y0 - PAD + py, gx = x0 - PAD + px;
+            // (bitwise on purpose: && would turn every slot into a branch)
+            const unsigned ok = (unsigned)(tid + u * NTH < PH * PW * 8) & (unsigned)((unsigned)gy < (unsigned)a.H) &
+                                (unsigned)((unsigned)gx < (unsigned)a.W);
+            rp[u] = ld16(sp, __umul24((unsigned)(gy * a.W + gx) & (0u - ok), cs4) + lane_off);
+            inpic |= ok << u;
+        }
     };
     auto store_patch = [&]() {
 #pragma unroll
@@ -183,18 +190,15 @@ __global__ __launch_bounds__(64 * NWAVE, NWAVE / 2) void conv_k32(const K32 a) {
             }
         }
     };
-    unsigned wofs[NW];  // this thread's float4s of a filter row: byte offsets, the same for every step
-#pragma unroll
-    for (int u = 0; u < NW; ++u) {
-        const int i = tid + u * NTH;
-        const int row = i / BN, col = i - row * BN;
-        wofs[u] = i < TPS * 8 * BN ? (unsigned)(row * a.Cout_pad + col) * 16u : 0u;
-    }
     auto load_w = [&](const Cursor &k) {
         const char *wsrc = (const char *)(a.wpack + ((size_t)(k.cg * T + k.st * TPS) * 8) * a.Cout_pad * 4 + (size_t)n0 * 4);
+        int t = tid;
+        asm volatile("" : "+v"(t));
 #pragma unroll
-        for (int u = 0; u < NW; ++u)
-            if (u + 1 < NW || tid + u * NTH < TPS * 8 * BN) rw[u] = ld16(wsrc, wofs[u]);
+        for (int u = 0; u < NW; ++u) {
+            const int i = t + u * NTH;  // float4 i of the filter row: [row = i / BN][col = i % BN], rows Cout_pad apart
+            if (u + 1 < NW || tid + u * NTH < TPS * 8 * BN) rw[u] = ld16(wsrc, (unsigned)((i / BN) * a.Cout_pad + (i % BN)) * 16u);
+        }
     };
     auto store_w = [&]() {
 #pragma unroll
@@ -321,8 +325,9 @@ __global__ __launch_bounds__(64 * NWAVE, NWAVE / 2) void conv_k32(const K32 a) {
     f32x4 rv[MT][NTW];
     K32_STAMP(57);
     K32_STAMP(58);
-    if (a.res) {  // (requesting these under the last step's MFMAs was tried: the compiler then keeps 64 registers for them
-                  // across the whole loop and spills)
+    if (a.res) {  // (requesting these under the last step's MFMAs was tried, also with the last step peeled off the loop:
+                  // the compiler keeps or spills their 32-64 registers; requesting only their cache lines there (LDS-DMA
+                  // loads into a sink) made the launch 3 % slower, tools/ab_probe.py)
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
