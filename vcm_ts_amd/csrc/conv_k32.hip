@@ -47,6 +47,17 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 #ifndef K32_ABLATE
 #define K32_ABLATE 0
 #endif
+// patch staging variants (developer A/B, tools/ab_probe.py): bit 0 = out-of-picture slots are read through a buffer
+// descriptor with an out-of-range offset (the hardware returns zeros: no select per value), bit 1 = the input activation
+// as max(s, s * slope) on the scaled value (two operations per value instead of multiply + compare + select)
+#ifndef K32_STAGE
+#define K32_STAGE 3
+#endif
+// epilogue variant (developer A/B): 1 = residual loads and output stores through buffer descriptors (scalar base + 32-bit
+// offset, masked lanes get an out-of-range offset: loads return zeros, stores are dropped -- no branch per access)
+#ifndef K32_EPI
+#define K32_EPI 1
+#endif
 
 namespace {
 
@@ -154,6 +165,9 @@ __global__ __launch_bounds__(64 * NWAVE, NWAVE / 2) void conv_k32(const K32 a) {
         asm volatile("" : "+v"(t));  // (opaque: keeps the compiler from hoisting the slot arithmetic back out of the loop)
         const unsigned lane_off = (t & 7) * 16u;
         inpic = 0;
+        // (K32_STAGE & 1) the image as a raw buffer: an offset at or beyond num_records reads as zeros
+        const unsigned img_bytes = (unsigned)(a.H * a.W) * cs4;  // (< 2^32: dcvc_conv2d_k32 checks)
+        [[maybe_unused]] const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)sp, 0, (int)img_bytes, 0x00020000);
 #pragma unroll
         for (int u = 0; u < NP; ++u) {
             const int i = t + u * NTH;
@@ -163,8 +177,13 @@ __global__ __launch_bounds__(64 * NWAVE, NWAVE / 2) void conv_k32(const K32 a) {
             // (bitwise on purpose: && would turn every slot into a branch)
             const unsigned ok = (unsigned)(tid + u * NTH < PH * PW * 8) & (unsigned)((unsigned)gy < (unsigned)a.H) &
                                 (unsigned)((unsigned)gx < (unsigned)a.W);
-            rp[u] = ld16(sp, __umul24((unsigned)(gy * a.W + gx) & (0u - ok), cs4) + lane_off);
-            inpic |= ok << u;
+            if (K32_STAGE & 1) {
+                const unsigned off = ok ? __umul24((unsigned)(gy * a.W + gx), cs4) + lane_off : img_bytes;
+                rp[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, 0, 0));
+            } else {
+                rp[u] = ld16(sp, __umul24((unsigned)(gy * a.W + gx) & (0u - ok), cs4) + lane_off);
+                inpic |= ok << u;
+            }
         }
     };
     auto store_patch = [&]() {
@@ -172,14 +191,31 @@ __global__ __launch_bounds__(64 * NWAVE, NWAVE / 2) void conv_k32(const K32 a) {
         for (int u = 0; u < NP; ++u) {
             const int i = tid + u * NTH;
             if (i < PH * PW * 8) {
-                f32x4 v = ((inpic >> u) & 1u) ? rp[u] : (f32x4){0.f, 0.f, 0.f, 0.f};
-                if (a.in_act) {
-                    v[0] = act(v[0], a.in_slope);
-                    v[1] = act(v[1], a.in_slope);
-                    v[2] = act(v[2], a.in_slope);
-                    v[3] = act(v[3], a.in_slope);
+                f32x4 v = rp[u];
+                if (!(K32_STAGE & 1)) v = ((inpic >> u) & 1u) ? v : (f32x4){0.f, 0.f, 0.f, 0.f};
+                f32x4 sv;
+                if (K32_STAGE & 2) {
+                    // LeakyReLU on the scaled value: max(s, s * slope) == 8 * (v > 0 ? v : v * slope) for 0 <= slope <= 1
+                    // (a power-of-two scale commutes with the rounding of v * slope; dcvc_conv2d_k32 checks the slope)
+                    sv = v * ACT_SCALE;
+                    if (a.in_act) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {  // (one v_max_f32: fmaxf would add a NaN-quieting operation per value)
+                            const float t = sv[e] * a.in_slope;
+                            float r;
+                            asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(sv[e]), "v"(t));
+                            sv[e] = r;
+                        }
+                    }
+                } else {
+                    if (a.in_act) {
+                        v[0] = act(v[0], a.in_slope);
+                        v[1] = act(v[1], a.in_slope);
+                        v[2] = act(v[2], a.in_slope);
+                        v[3] = act(v[3], a.in_slope);
+                    }
+                    sv = v * ACT_SCALE;
                 }
-                f32x4 sv = v * ACT_SCALE;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) sv[e] = __builtin_amdgcn_fmed3f(sv[e], -F16_MAX, F16_MAX);
                 const f16x4 hi = __builtin_convertvector(sv, f16x4);
@@ -325,14 +361,23 @@ __global__ __launch_bounds__(64 * NWAVE, NWAVE / 2) void conv_k32(const K32 a) {
     f32x4 rv[MT][NTW];
     K32_STAMP(57);
     K32_STAMP(58);
+    // (K32_EPI) the output / residual images as raw buffers: offset == num_records is out of range
+    const unsigned out_bytes = (unsigned)(Ho * Wo) * (unsigned)a.out_cs * 4u, res_bytes = (unsigned)(Ho * Wo) * (unsigned)a.res_cs * 4u;
+    [[maybe_unused]] const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc((void *)out_b, 0, (int)out_bytes, 0x00020000);
+    [[maybe_unused]] const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc((void *)res_b, 0, a.res ? (int)res_bytes : 0, 0x00020000);
     if (a.res) {  // (requesting these under the last step's MFMAs was tried, also with the last step peeled off the loop:
                   // the compiler keeps or spills their 32-64 registers; requesting only their cache lines there (LDS-DMA
                   // loads into a sink) made the launch 3 % slower, tools/ab_probe.py)
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
-            for (int n = 0; n < NTW; ++n)
-                rv[m][n] = ld16(res_b, ((okm >> (m * NTW + n)) & 1u) ? out_off(m, n, a.res_cs) : 0u);
+            for (int n = 0; n < NTW; ++n) {
+                const bool ok = (okm >> (m * NTW + n)) & 1u;
+                if (K32_EPI)
+                    rv[m][n] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_res, (int)(ok ? out_off(m, n, a.res_cs) : res_bytes), 0, 0));
+                else
+                    rv[m][n] = ld16(res_b, ok ? out_off(m, n, a.res_cs) : 0u);
+            }
     }
     f32x4 csum[NTW];
     float vmax = 0.f;  // largest |output| this lane stores (range guard)
@@ -363,11 +408,19 @@ __global__ __launch_bounds__(64 * NWAVE, NWAVE / 2) void conv_k32(const K32 a) {
                     v = v + rv[m][n];
                 }
             }
-            if ((okm >> (m * NTW + n)) & 1u) {
-                if (a.res2) v = ld16(res2_b, out_off(m, n, a.res2_cs)) + v;
-                if (a.chan_partial) csum[n] += v;
+            const bool ok = (okm >> (m * NTW + n)) & 1u;
+            if (K32_EPI && !a.res2 && !a.chan_partial) {
                 // range guard, always on (two v_max3_f32 per 4 outputs): an output beyond +-8188 would be clamped by
                 // a split-fp16 consumer.  An infinity is caught here; a NaN can only follow one.
+                const float m4 = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
+                vmax = fmaxf(vmax, ok ? m4 : 0.f);
+                if (!(K32_ABLATE & 4))
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) int, v), rs_out,
+                                                           (int)(ok ? out_off(m, n, a.out_cs) : out_bytes), 0, 0);
+                else asm volatile("" ::"v"(v));
+            } else if (ok) {
+                if (a.res2) v = ld16(res2_b, out_off(m, n, a.res2_cs)) + v;
+                if (a.chan_partial) csum[n] += v;
                 vmax = fmaxf(vmax, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
                 if (!(K32_ABLATE & 4)) *(f32x4 *)(out_b + out_off(m, n, a.out_cs)) = v;
                 else asm volatile("" ::"v"(v));
@@ -483,6 +536,15 @@ extern "C" int dcvc_conv2d_k32(const dcvc_conv_args *a, void *stream) {
         k.seg_C[s] = a->seg[s].C;
         k.seg_cs[s] = a->seg[s].cs;
     }
+    {  // output / residual images are addressed with 32-bit byte offsets (and as raw buffers)
+        const unsigned long long opix = (unsigned long long)a->Hin * a->Win * (a->pixel_shuffle ? 4 : 1);
+        if (opix * a->out_cs * 4ull > 0xfffffff0ull || (a->res && opix * a->res_cs * 4ull > 0xfffffff0ull) ||
+            (a->res2 && opix * a->res2_cs * 4ull > 0xfffffff0ull))
+            return DCVC_E_ARG;
+    }
+    if ((K32_STAGE & 2) && a->in_act && !(a->in_slope >= 0.f && a->in_slope <= 1.f)) return DCVC_E_ARG;
+    for (int s = 0; s < a->nseg; ++s)  // an image of a segment is addressed with 32-bit byte offsets (and as a raw buffer)
+        if ((unsigned long long)a->Hin * a->Win * a->seg[s].cs * 4ull > 0xfffffff0ull) return DCVC_E_ARG;
     k.nseg = a->nseg;
     k.H = a->Hin;
     k.W = a->Win;
