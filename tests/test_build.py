@@ -66,3 +66,24 @@ def test_makefile_does_not_filter_compiler_diagnostics():
     mk = open(os.path.join(CSRC, "Makefile")).read()
     assert "grep -v" not in mk
     assert "check-isa" in mk.split("all:")[1].splitlines()[0]
+
+
+@needs_toolchain
+def test_dominant_kernel_keeps_its_occupancy_and_does_not_spill():
+    """conv_k32<3,4,8> (half of the GPU time of a P picture) is built for FOUR waves per SIMD and TWO workgroups per CU:
+    at most 128 registers per lane and 80 KB of LDS -- and nothing in scratch: round 3 found two spilled staging offsets
+    whose reloads (vector-memory loads behind vmcnt(0)) sat in front of every chunk's patch request in the main loop
+    (DESIGN.md 4.1 item 3e).  Read from the shipped code object's metadata, so a compiler or source change that brings
+    a spill back or drops the occupancy fails here."""
+    res = check_isa.kernel_resources(os.path.join(CSRC, "libdcvc_hip.so"))
+    main = [v for k, v in res.items() if "conv_k32ILi3ELi4ELi8E" in k]
+    assert len(main) == 1, sorted(k for k in res if "conv_k32" in k)
+    k = main[0]
+    assert k["vgpr_count"] + k["agpr_count"] <= 128, k
+    assert k["vgpr_spill_count"] == 0 and k["sgpr_spill_count"] == 0 and k["private_segment_fixed_size"] == 0, k
+    assert k["group_segment_fixed_size"] <= 160 * 1024 // 2, k
+    assert k["max_flat_workgroup_size"] == 512, k
+    # every kernel of the library: metadata present, and no kernel needs more than a few dwords of scratch
+    assert len(res) > 50
+    worst = max(res.items(), key=lambda kv: kv[1]["vgpr_spill_count"])
+    assert worst[1]["vgpr_spill_count"] <= 16, worst

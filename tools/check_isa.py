@@ -44,6 +44,41 @@ def packed_fp32_census(lib_path):
     return out
 
 
+READELF = os.environ.get("LLVM_READELF", "/opt/rocm/lib/llvm/bin/llvm-readelf")
+
+
+def kernel_resources(lib_path):
+    """{kernel symbol: {"vgpr_count", "vgpr_spill_count", "sgpr_count", "group_segment_fixed_size", ...}} from the
+    amdhsa metadata notes of every gfx950 code object of the library (what the loader will give each kernel)."""
+    out = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        local = os.path.join(tmp, os.path.basename(lib_path))
+        shutil.copy(lib_path, local)
+        subprocess.run([OBJDUMP, "--offloading", local], cwd=tmp, check=True, stdout=subprocess.DEVNULL)
+        for name in sorted(os.listdir(tmp)):
+            if "gfx950" not in name:
+                continue
+            notes = subprocess.run([READELF, "--notes", os.path.join(tmp, name)], check=True, stdout=subprocess.PIPE, text=True).stdout
+            # amdhsa.kernels is a YAML list of records with alphabetically sorted keys: a kernel's record starts at
+            # .agpr_count and ends at .wavefront_size; .symbol names it (argument records in between have other keys)
+            cur = None
+            for line in notes.splitlines():
+                m = re.match(r"\s*-?\s*\.(\w+):\s*(.*)$", line)
+                if not m:
+                    continue
+                key, val = m.group(1), m.group(2).strip().strip("'")
+                if key == "agpr_count":
+                    cur = {}
+                if cur is None:
+                    continue
+                if key == "symbol":
+                    out[val[:-3] if val.endswith(".kd") else val] = cur
+                elif key in ("agpr_count", "vgpr_count", "vgpr_spill_count", "sgpr_count", "sgpr_spill_count",
+                             "group_segment_fixed_size", "private_segment_fixed_size", "max_flat_workgroup_size"):
+                    cur[key] = int(val)
+    return out
+
+
 def main(argv):
     bad = False
     for path in argv:
