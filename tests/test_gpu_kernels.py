@@ -235,6 +235,53 @@ def test_k32_conv_matches_fp64_and_the_32x32_kernel(eng_split, case):
     assert (o1 - o0).abs().max().item() < 2e-6 * scale + 2e-7 * want.abs().max().item()
 
 
+def test_k32_conv_writes_nothing_outside_its_output(eng_split):
+    """conv_k32's epilogue masks lanes (pixels beyond the picture in partial tiles, channels beyond Cout in the padded last
+    block) by giving their buffer stores an out-of-range offset, which the hardware drops, and reads out-of-picture patch
+    slots the same way.  Output and residual live inside larger sentinel-filled allocations here: every float before and
+    after the N*H*W*cs region must still be the sentinel, and the inside must equal conv_mfma's result on a dense tensor
+    within the usual bound."""
+    from vcm_ts_amd.engine import View
+
+    eng = eng_split
+    N, cin, cout, H, W = 2, 64, 96, 21, 45  # partial tiles both ways; Cout padded to 128: 32 masked channels in block 1
+    g = torch.Generator().manual_seed(321)
+    x = torch.randn(N, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(cin * 9)
+    b = torch.randn(cout, generator=g) * 0.1
+    r = torch.randn(N, cout, H, W, generator=g)
+    pk = eng.pack(("k32guard",), torch.nn.Parameter(w.cuda()), torch.nn.Parameter(b.cuda()), (cin,), False)
+    xin = to_view(eng, "k32g/in", x)
+    guard, sentinel = 4096, -12345.0
+    n_out = N * H * W * cout
+
+    def framed(fill):
+        big = torch.full((guard + n_out + guard,), sentinel, device="cuda")
+        if fill is not None:
+            big[guard : guard + n_out] = fill.permute(0, 2, 3, 1).reshape(-1).cuda()
+        return big, View(big, cout, 0, geom=(N, H, W, cout, big.data_ptr() + 4 * guard))
+
+    res_big, res = framed(r)
+    out_big, out = framed(None)
+    ref = eng.buf("k32g/ref", N, H, W, cout)
+    eng.k32_sizes, eng.k32_everywhere = (3,), True
+    try:
+        assert eng.k32_capable(pk, 1, out, res, None, None)
+        eng.conv(pk, [xin], out, out_slope=0.01, res=res)
+        eng.use_k32 = False
+        eng.conv(pk, [xin], ref, out_slope=0.01, res=to_view(eng, "k32g/res", r))
+    finally:
+        eng.use_k32, eng.k32_everywhere = True, False
+    torch.cuda.synchronize()
+    for big in (out_big, res_big):
+        assert (big[:guard] == sentinel).all() and (big[guard + n_out :] == sentinel).all()
+    got = out_big[guard : guard + n_out].reshape(N, H, W, cout).permute(0, 3, 1, 2)
+    assert not (got == sentinel).any()
+    want = eng.to_nchw(ref)
+    assert (got - want).abs().max().item() < 1e-4 * want.abs().max().item()
+    assert eng.read_status() == 0
+
+
 def test_k32_conv_flags_outputs_beyond_the_split_fp16_range(eng_split):
     """The always-on range guard of the k32 kernel: an output beyond +-8188 sets DCVC_STATUS_ACT_SATURATED."""
     eng = eng_split
