@@ -1,6 +1,6 @@
 """Same-box A/B of builds of libdcvc_hip.so on one convolution layer: every library is loaded in its own child process
 (DCVC_HIP_LIB), rounds are interleaved across the children so that clock / thermal drift hits all of them alike.
-usage: ab_probe.py lib1.so lib2.so ... [-- cin cout ks [H W]]"""
+usage: ab_probe.py lib1.so[:ENV=VAL[:ENV2=VAL2]] lib2.so ... [-- cin cout ks [H W]]   ("-" = the product library)"""
 import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if os.environ.get("AB_CHILD"):
@@ -34,10 +34,16 @@ if "--" in args:
     k = args.index("--"); extra = [int(v) for v in args[k + 1:]]; args = args[:k]
     shape[:len(extra)] = extra
 kids = []
-for lib in args:
-    env = dict(os.environ, AB_CHILD=",".join(map(str, shape)), DCVC_HIP_LIB=lib)
+for spec in args:
+    lib, *sets = spec.split(":")
+    env = dict(os.environ, AB_CHILD=",".join(map(str, shape)))
+    if lib != "-":
+        env["DCVC_HIP_LIB"] = lib
+    for kv in sets:
+        k_, v_ = kv.split("=", 1)
+        env[k_] = v_
     p = subprocess.Popen([sys.executable, os.path.abspath(__file__)], env=env, stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
-    assert p.stdout.readline().strip() == "ready", lib
+    assert p.stdout.readline().strip() == "ready", spec
     kids.append(p)
 times = [[] for _ in kids]
 for rnd in range(9):
