@@ -109,6 +109,9 @@ typedef struct {
                           /* left untouched, inputs above / below it are read as usual).  0, 0: the whole picture.     */
                           /* A host that runs consecutive layers band by band keeps a layer's output in the 256 MB    */
                           /* Infinity Cache until its consumer reads it (vcm_ts_amd/engine.py: banded launches).       */
+    int32_t pair_taps;    /* 1: wpack comes from dcvc_conv_pack_weights_paired (7x7, stride 1, ONE input segment of    */
+                          /* <= 8 channels, DCVC_PREC_FP16X3: SpyNet's first layer, flow_estimation.py MEBasic conv1): */
+                          /* two taps share a 16-deep K step instead of padding 8 channels to 16.  dcvc_conv2d only.  */
 } dcvc_conv_args;
 
 /* output rows per tile row of dcvc_conv2d / dcvc_conv2d_k32 for this kernel size and stride (the band granularity) */
@@ -129,6 +132,11 @@ int64_t dcvc_conv_pack_size(int32_t Cout, int32_t ks, int32_t nseg, const int32_
 int dcvc_conv_pack_weights(const float *w, const float *b, int32_t Cout, int32_t ks, int32_t nseg,
                            const int32_t *seg_C, int32_t pixel_shuffle, int32_t precision, float *wpack,
                            float *bpack);
+
+/* Tap-paired packing for dcvc_conv_args.pair_taps (7x7 filters, Cin <= 8, split fp16).  w is (Cout, Cin, 7, 7) as
+ * nn.Conv2d stores it; returns DCVC_E_RANGE when a |weight| >= 1023.5 had to be clamped. */
+int64_t dcvc_conv_pack_size_paired(int32_t Cout, int32_t Cin, int32_t *cout_pad);
+int dcvc_conv_pack_weights_paired(const float *w, const float *b, int32_t Cout, int32_t Cin, float *wpack, float *bpack);
 
 int dcvc_conv2d(const dcvc_conv_args *a, void *stream);
 

@@ -94,6 +94,60 @@ def test_split_fp16_conv_matches_fp64(eng_split, case):
     assert (got - want).abs().max().item() < 3e-6 * scale + 2e-7 * want.abs().max().item()
 
 
+PAIR_CASES = [
+    # cin, cout, H, W, N, in_slope, out_slope, residual
+    (8, 32, 40, 72, 1, None, 0.0, False),     # SpyNet MEBasic conv1 (flow_estimation.py): partial tiles both ways
+    (8, 32, 17, 45, 2, None, 0.0, False),     # two images, ragged
+    (6, 64, 33, 31, 1, 0.1, None, True),      # channel tail (6 of 8), 64-column variant, activation on load, residual
+    (3, 48, 8, 32, 1, None, 0.01, False),     # 3 channels, Cout padded to 64, exactly one tile
+]
+
+
+@pytest.mark.parametrize("case", PAIR_CASES, ids=[f"p{i}" for i in range(len(PAIR_CASES))])
+def test_tap_paired_7x7_conv_matches_fp64_and_the_unpaired_kernel(eng_split, case):
+    """dcvc_conv2d with pair_taps (7x7, <= 8 input channels: two taps per 16-deep K step, weights from
+    dcvc_conv_pack_weights_paired) against an fp64 reference within the split-fp16 bound, and against the unpaired
+    kernel on the same layer (same operand values, another grouping of the sum)."""
+    cin, cout, H, W, N, in_slope, out_slope, use_res = case
+    eng = eng_split
+    g = torch.Generator().manual_seed(PAIR_CASES.index(case) + 400)
+    mag = torch.tensor([1e-3, 1.0, 20.0])[torch.randint(0, 3, (N, cin, 1, 1), generator=g)]
+    x = torch.randn(N, cin, H, W, generator=g) * mag
+    w = torch.randn(cout, cin, 7, 7, generator=g) / math.sqrt(cin * 49)
+    b = torch.randn(cout, generator=g) * 0.1
+    xin = x.double() if in_slope is None else F.leaky_relu(x.double(), in_slope)
+    want = F.conv2d(xin, w.double(), b.double(), padding=3)
+    scale = F.conv2d(xin.abs(), w.double().abs(), None, padding=3).max().item()
+    if out_slope is not None:
+        want = F.leaky_relu(want, out_slope)
+    res = None
+    if use_res:
+        r = torch.randn(want.shape, generator=g)
+        res = to_view(eng, "pair/res", r)
+        want = want + r.double()
+    pk = eng.pack(("pair", case), torch.nn.Parameter(w.cuda()), torch.nn.Parameter(b.cuda()), (cin,), False)
+    xv = to_view(eng, "pair/in", x)
+    outs = {}
+    try:
+        for paired in (True, False):
+            eng.use_pairs = paired
+            assert eng.pair_capable(pk, 1) == paired
+            out = eng.buf(f"pair/out{int(paired)}", N, H, W, cout)
+            out.base.fill_(float("nan"))
+            for rep in range(2):  # twice: same bits
+                eng.conv(pk, [xv], out, in_slope=in_slope, out_slope=out_slope, res=res)
+                got = eng.to_nchw(out)
+                if rep:
+                    assert torch.equal(got, outs[paired])
+                outs[paired] = got
+    finally:
+        eng.use_pairs = True
+    o1, o0 = outs[True].cpu().double(), outs[False].cpu().double()
+    assert not torch.isnan(o1).any()
+    assert (o1 - want).abs().max().item() < 3e-6 * scale + 2e-7 * want.abs().max().item()
+    assert (o1 - o0).abs().max().item() < 2e-6 * scale + 2e-7 * want.abs().max().item()
+
+
 SMALL_CASES = [
     # cin segments, cout, ks, H, W, N, in_slope, out_slope, residual
     ((32,), 16, 7, 40, 72, 1, None, 0.0, False),       # SpyNet conv4

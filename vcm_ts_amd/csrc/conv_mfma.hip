@@ -91,12 +91,18 @@ __device__ __forceinline__ void split_f16(float v, _Float16 &hi, _Float16 &lo) {
     lo = (_Float16)(v - (float)hi);
 }
 
-template <int KS, int S, int RPW, int NT, bool SPLIT>
+// PAIR (7x7, one segment of <= 8 input channels, split mode: SpyNet's first layer): a 16-deep K step would be half
+// zero padding.  Instead the LDS record of patch pixel (y, x) carries the 8 channels of (y, x) in its lower half and
+// the 8 channels of (y, x + 1) in its upper half, and the filter is packed in tap PAIRS (kx = 2j, 2j + 1; the pair of
+// kx = 6 is a zero tap): 4 K steps per filter row instead of 7, the fragment reads unchanged.  Weights from
+// dcvc_conv_pack_weights_paired; selected by dcvc_conv_args.pair_taps.
+template <int KS, int S, int RPW, int NT, bool SPLIT, bool PAIR = false>
 __global__ __launch_bounds__(256, 2) void conv_mfma(const ConvK a) {
+    static_assert(!PAIR || (KS == 7 && S == 1 && SPLIT), "tap pairing is built for the 7x7 split-fp16 layers");
     constexpr int BH = 4 * RPW, BW = 32, BN = 32 * NT;
     constexpr int PH = (BH - 1) * S + KS, PW = (BW - 1) * S + KS, PAD = KS / 2;
-    constexpr int T = KS * KS;
-    constexpr int TPS = (KS == 3 && S == 1) ? 9 : KS;  // taps staged in LDS at a time
+    constexpr int T = PAIR ? KS * 4 : KS * KS;           // K steps of a chunk (taps, or tap pairs)
+    constexpr int TPS = PAIR ? 4 : (KS == 3 && S == 1) ? 9 : KS;  // of which staged in LDS at a time
     constexpr int NST = T / TPS;
     constexpr int EPI_LD = BN + 4;  // floats per pixel row of the epilogue's transpose tile
     // epilogue: transpose tiles of the four waves, then 4 x BN floats for the fused channel sums
@@ -152,7 +158,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma(const ConvK a) {
     for (int u = 0; u < NP; ++u) {
         const int i = tid + u * 256;
         const int p = i >> 2;
-        const int py = p / PW, px = p - py * PW;
+        const int py = p / PW, px = p - py * PW + (PAIR ? (i & 3) >> 1 : 0);  // (PAIR: the record's upper half is the next pixel)
         const int gy = y0 * S - PAD + py, gx = x0 * S - PAD + px;
         const bool ok = i < PH * PW * 4 && gy >= 0 && gy < a.Hin && gx >= 0 && gx < a.Win;
         poff[u] = ok ? gy * a.Win + gx : 0;
@@ -161,7 +167,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma(const ConvK a) {
     auto load_patch = [&](const Cursor &k) {
         const int C = a.seg_C[k.s], cs = a.seg_cs[k.s];
         const float *sp = a.seg_ptr[k.s] + (size_t)img * a.Hin * a.Win * cs;
-        const int c = k.c0 + (tid & 3) * 4;
+        const int c = PAIR ? (tid & 1) * 4 : k.c0 + (tid & 3) * 4;
         const int cc = c < C ? c : 0;  // chunk tail: load channel 0, zeroed at store time
 #pragma unroll
         for (int u = 0; u < NP; ++u) rp[u] = *(const f32x4 *)(sp + (size_t)poff[u] * cs + cc);
@@ -172,7 +178,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma(const ConvK a) {
         for (int u = 0; u < NP; ++u) {
             const int i = tid + u * 256;
             if (i < PH * PW * 4) {
-                const int c = k.c0 + (i & 3) * 4;
+                const int c = PAIR ? (i & 1) * 4 : k.c0 + (i & 3) * 4;
                 f32x4 v = ((inpic >> u) & 1u) && c < C ? rp[u] : (f32x4){0.f, 0.f, 0.f, 0.f};
                 if (c + 3 >= C) {  // channels past the segment's end read as zero
                     if (c + 1 >= C) v[1] = 0.f;
@@ -235,7 +241,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma(const ConvK a) {
         const int a_st = (TPS == T) ? 0 : cur.st * PW * LDK;  // staged by filter row
 #pragma unroll
         for (int tt = 0; tt < TPS; ++tt) {
-            const int ky = (TPS == T) ? tt / KS : 0, kx = (TPS == T) ? tt % KS : tt;
+            const int ky = (TPS == T) ? tt / KS : 0, kx = PAIR ? 2 * tt : (TPS == T) ? tt % KS : tt;
             if (!SPLIT) {
 #pragma unroll
                 for (int k2 = 0; k2 < 2; ++k2) {
@@ -441,7 +447,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma(const ConvK a) {
 }
 
 
-template <int KS, int S, int RPW, int NT>
+template <int KS, int S, int RPW, int NT, bool PAIR = false>
 int launch(ConvK &k, int N, hipStream_t st, int precision) {
     constexpr int BH = 4 * RPW, BN = 32 * NT;
     k.ntx = (k.Wout + 31) / 32;
@@ -459,7 +465,9 @@ int launch(ConvK &k, int N, hipStream_t st, int precision) {
     if (k.ty0 < 0 || k.ty0 >= k.nty) return DCVC_E_ARG;
     const int rows = k.band_rows > 0 ? (k.band_rows < k.nty - k.ty0 ? k.band_rows : k.nty - k.ty0) : k.nty;
     dim3 grid(gx, (unsigned)rows, (unsigned)N);
-    if (precision == DCVC_PREC_FP16X3)
+    if (PAIR)
+        hipLaunchKernelGGL((conv_mfma<KS, S, RPW, NT, true, PAIR>), grid, dim3(256), 0, st, k);
+    else if (precision == DCVC_PREC_FP16X3)
         hipLaunchKernelGGL((conv_mfma<KS, S, RPW, NT, true>), grid, dim3(256), 0, st, k);
     else
         hipLaunchKernelGGL((conv_mfma<KS, S, RPW, NT, false>), grid, dim3(256), 0, st, k);
@@ -530,6 +538,43 @@ extern "C" int dcvc_conv_pack_weights(const float *w, const float *b, int32_t Co
     return DCVC_OK;
 }
 
+// Tap-paired packing of a 7x7 layer with one input segment of <= 8 channels (split fp16 only; see PAIR above):
+// K step (ky, j) holds tap (ky, 2j) in channel half 0 and tap (ky, 2j + 1) in half 1 (zero for kx = 7).
+// wpack rows [(ky * 4 + j)][hi h0, hi h1, lo h0, lo h1][n][8 fp16].
+extern "C" int64_t dcvc_conv_pack_size_paired(int32_t Cout, int32_t Cin, int32_t *cout_pad) {
+    if (Cout <= 0 || Cin <= 0 || Cin > 8) return DCVC_E_ARG;
+    const int cp = round_up(Cout, 32);
+    if (cout_pad) *cout_pad = cp;
+    return (int64_t)7 * 4 * 4 * cp * 4;
+}
+
+extern "C" int dcvc_conv_pack_weights_paired(const float *w, const float *b, int32_t Cout, int32_t Cin, float *wpack, float *bpack) {
+    int32_t cp = 0;
+    const int64_t total = dcvc_conv_pack_size_paired(Cout, Cin, &cp);
+    if (total < 0 || !w || !wpack || !bpack) return DCVC_E_ARG;
+    memset(wpack, 0, (size_t)total * sizeof(float));
+    memset(bpack, 0, (size_t)cp * sizeof(float));
+    _Float16 *base = (_Float16 *)wpack;
+    bool clamped = false;
+    for (int ky = 0; ky < 7; ++ky)
+        for (int kx = 0; kx < 7; ++kx) {
+            const int step = ky * 4 + (kx >> 1), h = kx & 1;
+            for (int c = 0; c < Cin; ++c)
+                for (int n = 0; n < Cout; ++n) {
+                    float sv = w[((size_t)n * Cin + c) * 49 + ky * 7 + kx] * WGT_SCALE;
+                    if (!(fabsf(sv) <= F16_MAX)) {
+                        clamped = true;
+                        sv = sv > 0.f ? F16_MAX : -F16_MAX;
+                    }
+                    const _Float16 hi = (_Float16)sv, lo = (_Float16)(sv - (float)hi);
+                    base[(((size_t)step * 4 + h) * cp + n) * 8 + c] = hi;
+                    base[(((size_t)step * 4 + 2 + h) * cp + n) * 8 + c] = lo;
+                }
+        }
+    for (int n = 0; n < Cout; ++n) bpack[n] = b ? b[n] : 0.f;
+    return clamped ? DCVC_E_RANGE : DCVC_OK;
+}
+
 // rows of a workgroup's output tile per (kernel size, stride): 4 * RPW of the instantiations below
 static int tile_rows(int ks, int stride) { return stride == 2 ? 4 : 8; }
 
@@ -598,7 +643,12 @@ extern "C" int dcvc_conv2d(const dcvc_conv_args *a, void *stream) {
         case 31:
             return wide ? launch<3, 1, 2, 2>(k, a->N, st, a->precision) : launch<3, 1, 2, 1>(k, a->N, st, a->precision);
         case 32: return wide ? launch<3, 2, 1, 2>(k, a->N, st, a->precision) : launch<3, 2, 1, 1>(k, a->N, st, a->precision);
-        case 71: return wide ? launch<7, 1, 2, 2>(k, a->N, st, a->precision) : launch<7, 1, 2, 1>(k, a->N, st, a->precision);
+        case 71:
+            if (a->pair_taps) {  // weights from dcvc_conv_pack_weights_paired
+                if (a->nseg != 1 || a->seg[0].C > 8 || a->precision != DCVC_PREC_FP16X3 || a->pixel_shuffle) return DCVC_E_ARG;
+                return wide ? launch<7, 1, 2, 2, true>(k, a->N, st, a->precision) : launch<7, 1, 2, 1, true>(k, a->N, st, a->precision);
+            }
+            return wide ? launch<7, 1, 2, 2>(k, a->N, st, a->precision) : launch<7, 1, 2, 1>(k, a->N, st, a->precision);
         default: return DCVC_E_ARG;
     }
 }

@@ -74,7 +74,7 @@ class View:
 
 class PackedConv:
     __slots__ = ("w", "b", "ks", "Cout", "Cout_pad", "seg_C", "ps", "version", "precision", "weight", "bias",
-                 "cin_slice", "key", "small", "k32", "host", "job")
+                 "cin_slice", "key", "small", "k32", "paired", "host", "job")
 
 
 class Engine:
@@ -103,6 +103,7 @@ class Engine:
         # dcvc_conv2d_k32 (16x16x32 MFMA, 32-channel chunks) for the stride-1 3x3 / 1x1 layers it covers; DCVC_K32=0
         # keeps them on dcvc_conv2d (developer A/B switch: an encoder and its decoder must use the same setting)
         self.use_k32 = os.environ.get("DCVC_K32", "1") != "0"
+        self.use_pairs = os.environ.get("DCVC_PAIR_TAPS", "1") != "0"  # tap-paired 7x7 kernel for layers with <= 8 input channels
         self.k32_everywhere = False  # tests: route every layer the kernel covers to it, whatever its size
         self.k32_sizes = tuple(int(k) for k in os.environ.get("DCVC_K32_SIZES", "3").split(","))  # kernel sizes it takes (1x1 layers are HBM-bound: conv_mfma's full-line stores are 10-15 % faster there)
         # fp16x3 mode clamps |activation| > 8188 on load; every convolution launch of that mode flags outputs beyond
@@ -369,6 +370,38 @@ class Engine:
         pk.small = q
         return q
 
+    def pack_paired(self, pk: PackedConv) -> PackedConv:
+        """The same 7x7 layer (one segment of <= 8 input channels) packed in tap pairs for dcvc_conv2d with pair_taps."""
+        q = getattr(pk, "paired", None)
+        if q is not None and q.version == pk.version:
+            return q
+        w = pk.weight.detach().float().cpu()
+        if pk.cin_slice is not None:
+            w = w[:, pk.cin_slice[0] : pk.cin_slice[1]]
+        w = w.contiguous().numpy()
+        b = None if pk.bias is None else pk.bias.detach().float().cpu().contiguous().numpy()
+        cpad = C.c_int32()
+        n = self.L.dcvc_conv_pack_size_paired(pk.Cout, pk.seg_C[0], C.byref(cpad))
+        if n < 0:
+            raise lib.KernelError(f"conv_pack_size_paired({pk.key})")
+        wp = np.empty(n, np.float32)
+        bp = np.empty(cpad.value, np.float32)
+        lib.check(self.L.dcvc_conv_pack_weights_paired(w.ctypes.data, None if b is None else b.ctypes.data, pk.Cout, pk.seg_C[0],
+                                                       wp.ctypes.data, bp.ctypes.data),
+                  f"conv_pack_weights_paired({pk.key}) [status -3: a |weight| >= 1023.5 does not fit split fp16, use precision='fp32']")
+        q = PackedConv()
+        q.w, q.b = torch.from_numpy(wp).to(self.device), torch.from_numpy(bp).to(self.device)
+        q.ks, q.Cout, q.Cout_pad, q.seg_C, q.ps, q.version, q.key = pk.ks, pk.Cout, cpad.value, pk.seg_C, False, pk.version, pk.key
+        pk.paired = q
+        return q
+
+    def pair_capable(self, pk: PackedConv, stride) -> bool:
+        """7x7 stride-1 layers with ONE input segment of <= 8 channels (SpyNet's first layer, MEBasic conv1) in fast mode:
+        two taps share a 16-deep K step (dcvc_conv_args.pair_taps).  Geometry of the layer only: the same decision on the
+        encoder and the decoder side.  Host-packed weights only (a training step packs on the device, plain layout)."""
+        return (self.precision == "fp16x3" and self.tape is None and self.use_pairs and getattr(pk, "host", False)
+                and pk.ks == 7 and stride == 1 and len(pk.seg_C) == 1 and pk.seg_C[0] <= 8 and not pk.ps and pk.Cout > 16)
+
     def pack_k32(self, pk: PackedConv) -> PackedConv:
         """The same layer packed for dcvc_conv2d_k32 (32-channel chunks), cached beside the other packing."""
         q = getattr(pk, "k32", None)
@@ -468,7 +501,9 @@ class Engine:
         a.in_act, a.in_slope = (0, 0.0) if in_slope is None else (1, in_slope)
         small = band is None and self.small_capable(pk, stride, gate, res2, chan_partial)
         k32 = not small and self.k32_capable(pk, stride, out, res, res2, gate)
-        wq = self.pack_small(pk) if small else (self.pack_k32(pk) if k32 else pk)
+        paired = not small and not k32 and self.pair_capable(pk, stride)
+        wq = self.pack_small(pk) if small else (self.pack_k32(pk) if k32 else (self.pack_paired(pk) if paired else pk))
+        a.pair_taps = int(paired)
         a.wpack, a.bpack = wq.w.data_ptr(), wq.b.data_ptr()
         a.ks, a.stride, a.Cout, a.Cout_pad = pk.ks, stride, pk.Cout, wq.Cout_pad
         pad = pk.ks // 2

@@ -70,7 +70,7 @@ class ConvArgs(C.Structure):
         ("out", C.c_void_p), ("out_cs", C.c_int32), ("out_act", C.c_int32), ("out_slope", C.c_float),
         ("pixel_shuffle", C.c_int32), ("res", C.c_void_p), ("res_cs", C.c_int32), ("res_gate", C.c_void_p),
         ("res2", C.c_void_p), ("res2_cs", C.c_int32), ("precision", C.c_int32), ("status", C.c_void_p),
-        ("chan_partial", C.c_void_p), ("tile_row0", C.c_int32), ("tile_rows", C.c_int32),
+        ("chan_partial", C.c_void_p), ("tile_row0", C.c_int32), ("tile_rows", C.c_int32), ("pair_taps", C.c_int32),
     ]
 
 
@@ -135,6 +135,7 @@ i32, i64, f32, vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
 _SIGS = {
     "dcvc_conv2d": [C.POINTER(ConvArgs), vp],
     "dcvc_conv_pack_weights": [vp, vp, i32, i32, i32, vp, i32, i32, vp, vp],
+    "dcvc_conv_pack_weights_paired": [vp, vp, i32, i32, vp, vp],
     "dcvc_conv2d_small": [C.POINTER(ConvArgs), vp],
     "dcvc_conv_small_pack_weights": [vp, vp, i32, i32, i32, vp, vp, vp],
     "dcvc_conv2d_k32": [C.POINTER(ConvArgs), vp],
@@ -189,7 +190,7 @@ _SIGS = {
     "dcvc_drans_build_lut": [vp, i32, i32, vp, vp],
 }
 
-HIP_SYMBOLS = sorted(list(_SIGS) + ["dcvc_cdf_table_cols", "dcvc_conv_pack_size", "dcvc_conv_small_pack_bytes", "dcvc_conv_k32_pack_bytes", "dcvc_conv_tile_rows", "dcvc_conv_chan_partial_parts", "dcvc_hip_version", "dcvc_conv_wgrad_scratch_min",
+HIP_SYMBOLS = sorted(list(_SIGS) + ["dcvc_cdf_table_cols", "dcvc_conv_pack_size", "dcvc_conv_pack_size_paired", "dcvc_conv_small_pack_bytes", "dcvc_conv_k32_pack_bytes", "dcvc_conv_tile_rows", "dcvc_conv_chan_partial_parts", "dcvc_hip_version", "dcvc_conv_wgrad_scratch_min",
                                     "dcvc_drans_default_lanes", "dcvc_drans_scratch_words"])
 RANS_SYMBOLS = [
     "dcvc_rans_encoder_create", "dcvc_rans_encoder_destroy", "dcvc_rans_encoder_reset",
@@ -210,6 +211,8 @@ def hip():
         L.dcvc_pack_plan_destroy.restype = None
         L.dcvc_conv_pack_size.argtypes = [i32, i32, i32, vp, C.POINTER(i32)]
         L.dcvc_conv_pack_size.restype = i64
+        L.dcvc_conv_pack_size_paired.argtypes = [i32, i32, C.POINTER(i32)]
+        L.dcvc_conv_pack_size_paired.restype = i64
         L.dcvc_cdf_table_cols.argtypes = []
         L.dcvc_cdf_table_cols.restype = i32
         L.dcvc_conv_chan_partial_parts.argtypes = [i32, i32, i32, i32]
