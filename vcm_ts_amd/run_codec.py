@@ -165,6 +165,7 @@ def encode_folder(frames_dir, bin_dir, recon_dir=None, gop=32, q=(1.0, 1.0, 1.0)
                 if not ring:
                     ring = [torch.empty(rgb.shape, dtype=torch.uint8).pin_memory() for _ in range(3)]
                     done = [None] * len(ring)
+                assert tuple(rgb.shape) == tuple(ring[0].shape), "all frames must have one size"
                 k = n % len(ring)
                 if done[k] is not None:
                     done[k].synchronize()  # the copy that last read this pinned buffer (three pictures ago)
