@@ -195,44 +195,54 @@ class GopQuality:
         return 10.0 * np.log10(1.0 / mse)
 
 
-def files_workload(args, dev, n_frames):
+def files_workload(args, dev, n_frames, nets=None):
     """the reference's file loop (video_coder.run_dcvc: PNG in, one .bin per picture out) around the same
-    encoder, reported SEPARATELY from `value`: PNG decode + host->device + encode + rANS + .bin write per picture, one
-    GOP stream, from a temporary folder of synthetic 8-bit PNGs (written untimed).  vcm_ts_amd/run_codec.py."""
+    encoder, reported SEPARATELY from `value`: PNG decode + host->device + encode + rANS + .bin write per picture, from a
+    temporary folder of synthetic 8-bit PNGs (written untimed).  vcm_ts_amd/run_codec.py.  Round 4: the folder's GOPs go
+    through ConcurrentGopEncoder like the headline (args.gop_streams GOPs in flight, one shared pool of PNG-decoding
+    threads; .bin bytes identical to the one-stream loop, which is timed beside it).
+    nets: list of (i_frame_net, p_frame_net) pairs to reuse (one per GOP stream)."""
     import shutil
     import tempfile
     import time
+    from concurrent.futures import ThreadPoolExecutor
 
-    from vcm_ts_amd.run_codec import encode_folder, save_torch_image
+    from vcm_ts_amd.run_codec import _nets, _save_array, encode_folder
 
+    K = max(1, args.gop_streams)
     tmp = tempfile.mkdtemp(prefix="dcvc_files_")
     try:
         src, dst = os.path.join(tmp, "png"), os.path.join(tmp, "bin")
         os.makedirs(src)
-        for t, f in enumerate(synth_sequence(dev, n_frames, args.height, args.width, 11)):
-            save_torch_image(f, os.path.join(src, f"im{str(t + 1).zfill(5)}.png"))
+        with ThreadPoolExecutor(max_workers=8) as pool:  # (untimed) PNG encoding of noise is slow: spread it
+            for t, f in enumerate(synth_sequence(dev, n_frames, args.height, args.width, 11)):
+                pool.submit(_save_array, f.squeeze(0).permute(1, 2, 0).cpu().numpy(), os.path.join(src, f"im{str(t + 1).zfill(5)}.png"))
         png_bytes = sum(os.path.getsize(os.path.join(src, n)) for n in os.listdir(src))
-        from vcm_ts_amd.run_codec import _nets
+        if nets is None:  # built once, outside the timed loop (run_dcvc loads its models before its loop too)
+            nets = [_nets(dev, args.precision) for _ in range(K)]
+        common = dict(gop=args.gop, q=(1.0, 1.0, 1.0), device=str(dev), precision=args.precision)
+        encode_folder(src, dst, None, max_frames=min(n_frames, args.gop + 2), nets=nets, gop_streams=K, **common)  # warm-up
 
-        nets = _nets(dev, args.precision)  # built once, outside the timed loop (run_dcvc loads its models before its loop too)
-        encode_folder(src, dst, None, args.gop, (1.0, 1.0, 1.0), str(dev), args.precision, max_frames=3, nets=nets)  # warm-up
-
-        def timed(io_workers):
+        def timed(io_workers, streams):
             shutil.rmtree(dst, ignore_errors=True)
             torch.cuda.synchronize(dev)
             t0 = time.time()
-            bits, size = encode_folder(src, dst, None, args.gop, (1.0, 1.0, 1.0), str(dev), args.precision, io_workers=io_workers, nets=nets)
+            bits, size = encode_folder(src, dst, None, io_workers=io_workers, nets=nets, gop_streams=streams, **common)
             torch.cuda.synchronize(dev)
             return time.time() - t0, bits, size
 
-        dt_inline, _, _ = timed(0)   # PNGs decoded in the encode loop, as run_dcvc does
-        dt, bits, size = timed(8)    # run_codec's default: 8 host threads decode PNGs ahead of the encoder
+        dt_inline, _, _ = timed(0, 1)   # PNGs decoded in the encode loop, one GOP at a time, as run_dcvc does
+        dt_one, bits_one, _ = timed(8, 1)  # round 3's loop: 8 reader threads, one GOP stream
+        dt, bits, size = timed(8, K)    # run_codec --gop-streams K: the folder's GOPs in flight together
+        assert bits == bits_one, "the same .bin sizes whatever the number of GOP streams"
         return {"value": round(len(bits) / dt, 3), "unit": "frames/s", "frames": len(bits), "ms_per_frame": round(dt / len(bits) * 1e3, 2),
-                "io_threads": 8, "inline_io_frames_per_s": round(len(bits) / dt_inline, 3),
+                "io_threads": 8, "gop_streams": min(K, (len(bits) + args.gop - 1) // args.gop),
+                "one_gop_stream_frames_per_s": round(len(bits) / dt_one, 3),
+                "inline_io_frames_per_s": round(len(bits) / dt_inline, 3),
                 "png_mbytes_read": round(png_bytes / 1e6, 1), "bin_mbytes_written": round(sum(bits) / 8e6, 1),
                 "workload": f"run_codec encode of a folder of {len(bits)} synthetic {size[1]}x{size[0]} PNGs into .bin files (GOP "
-                            f"{args.gop}, one GOP stream, PNG decode and file writes inside the timed region; noise PNGs are the "
-                            f"slowest to decode); = bench.py --workload files"}
+                            f"{args.gop}, {K} GOPs in flight, PNG decode and file writes inside the timed region; noise PNGs are "
+                            f"the slowest to decode); = bench.py --workload files"}
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
 
@@ -384,7 +394,7 @@ def main():
     if args.workload == "files":
         if world != 1:
             raise SystemExit("bench.py --workload files is a one-GPU measurement")
-        r = files_workload(args, dev, args.gop)
+        r = files_workload(args, dev, args.gop * max(1, args.gop_streams))
         print(json.dumps({"metric": "encoded frames/sec at 1920x1080 GOP-32, PNG folder in, .bin folder out", "value": r["value"],
                           "unit": "frames/s", "n_gpus": 1, "steps": 1, "warmup": 0, "ms_per_step": round(r["ms_per_frame"] * r["frames"], 2),
                           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -448,6 +458,7 @@ def main():
         return
 
     bits_gop0 = [0]
+    last_coded = [None]
 
     def work():
         b = 0
@@ -455,9 +466,22 @@ def main():
             res = cenc.encode_gops(seqs, q_i, q_mv, q_y)
             b = sum(r[1] for r in res)
             bits_gop0[0] = res[0][1]
+            last_coded[0] = res[0][0]
         return b
 
+    # what a rank costs the HOST while it codes (for sizing an 8-rank node without having one):
+    # CPU seconds of this process over the timed region (every thread: the feeder, the rANS coder, torch's helpers),
+    # its thread count, and the device memory it holds
+    cpu0 = time.process_time()
     dt, bits, dt_local = timed_region(work, dev, with_local=True)
+    host_cpu_s = time.process_time() - cpu0
+    try:
+        host_threads = len(os.listdir("/proc/self/task"))
+    except OSError:
+        host_threads = None
+    import hashlib
+
+    payload_sha = hashlib.sha256(b"".join(c[2] for c in last_coded[0])).hexdigest()[:16]
     bits = bits / K  # per GOP
     frames_total = K * args.gop * args.steps * world
     fps = frames_total / dt
@@ -543,6 +567,16 @@ def main():
                    "parallelism": f"gop-sharded x{world} GPUs x{K} concurrent GOP streams per GPU",
                    "gops_per_step_per_gpu": K, "frames_per_step_per_gpu": K * args.gop,
                    "one_gop_stream_frames_per_s": one_stream,
+                   "host_cpu_s_per_frame": round(host_cpu_s / (K * args.gop * args.steps), 5),
+                   "host_cpu_cores_busy": round(host_cpu_s / dt_local, 2),
+                   "host_threads": host_threads,
+                   "hbm_bytes_reserved": int(torch.cuda.memory_reserved(dev)),
+                   "hbm_bytes_workspaces": int(sum(e_.i_net.engine().bytes_reserved() + e_.p_net.engine().bytes_reserved()
+                                                   for e_ in cenc.encoders)),
+                   "host_note": "per RANK: CPU seconds of this process per coded frame over the timed region (all threads: "
+                                "feeder, rANS coder), cores kept busy, threads alive, device memory held (caching allocator / "
+                                "the engines' named workspaces); an 8-rank node needs 8 x these",
+                   "payload_sha16_gop0": payload_sha,
                    "device": torch.cuda.get_device_name(dev), "device_uuid": str(getattr(torch.cuda.get_device_properties(dev), "uuid", "")),
                    "bits_per_gop": int(bits), "bpp": round(bits / (args.gop * args.height * args.width), 4),
                    "psnr_db_gop_mean": round(float(psnr_fast.mean()), 4),
@@ -591,7 +625,8 @@ def main():
                          "workload": f"decode of the same {K} GOPs (reference bitstream: 3 / 6 host rANS round trips per I / P "
                                      "picture), one host thread and HIP stream per GOP; = bench.py --workload decode"}
         del coded
-        out["files"] = files_workload(args, dev, 16)  # PNG -> .bin loop, I/O inside the timed region
+        # PNG -> .bin loop, I/O inside the timed region: K whole GOPs, on the encoders' own nets
+        out["files"] = files_workload(args, dev, K * args.gop, nets=[(e_.i_net, e_.p_net) for e_ in cenc.encoders])
         for e_ in cenc.encoders:  # free the 1080p workspaces before the training model allocates its own
             e_.i_net.engine().release()
             e_.p_net.engine().release()

@@ -159,11 +159,16 @@ int dcvc_conv2d_small(const dcvc_conv_args *a, void *stream);
  * DCVC_PREC_FP16X3, stride 1, 16-byte-aligned epilogue ((Cout or Cout/4 with pixel shuffle) % 4 == 0 and aligned
  * out / res / res2); `status` is cheap here (two VALU per four outputs) and meant to be always passed.  Weights from
  * dcvc_conv_k32_pack_weights (HOST; returns DCVC_E_RANGE with the buffers written, clamped, when a |weight| >= 1023.5).
- * Deterministic, but not bit-identical to dcvc_conv2d: the instruction sums 32 products per step instead of 16. */
+ * Deterministic, but not bit-identical to dcvc_conv2d: the instruction sums 32 products per step instead of 16.
+ * Limits (DCVC_E_ARG beyond them; callers fall back to dcvc_conv2d): an image of any operand below 4 GiB, fewer
+ * than 2^24 output pixels per image (after pixel shuffle), channel strides below 2^22 floats. */
 int64_t dcvc_conv_k32_pack_bytes(int32_t Cout, int32_t ks, int32_t nseg, const int32_t *seg_C, int32_t *cout_pad);
 int dcvc_conv_k32_pack_weights(const float *w, const float *b, int32_t Cout, int32_t ks, int32_t nseg,
                                const int32_t *seg_C, int32_t pixel_shuffle, void *wpack, float *bpack);
 int dcvc_conv2d_k32(const dcvc_conv_args *a, void *stream);
+/* Developer A/B hook: waves per workgroup (8, the default, or 4) of the 64-output-channel 3x3 kernel.  Results are
+ * bit-identical either way (sums inside a tile are ordered by tile row, not by wave); process-wide, not thread-safe. */
+int dcvc_conv_k32_set_waves(int32_t waves);
 
 /* ---- resampling ------------------------------------------------------------------------ */
 /* out(n,y,x,c) = bilinear(src(n,.,.,c), x + flow(n,y,x,0), y + flow(n,y,x,1)), border clamp */
@@ -231,6 +236,10 @@ typedef struct {
     const float *idx_edges; /* device, 256 floats: edge[k-1] = smallest fp32 scale whose build_indexes value
                                (entropy_models.py:264-268, torch-CPU fp32) is >= k, for k = 1..255; edge[255] =
                                +inf.  index(s) = number of edges <= s.  Needed whenever idx is written. */
+    const float *forced_q; /* encoder only, NULL in every product call: (N,H,W,C) rounded residuals to use INSTEAD of
+                              round(y / q_step - mean) at the positions of this step -- "teacher forcing" with symbol
+                              planes recorded from the reference, so that a parity test is not derailed by a value
+                              that sits on a rounding tie (tests/test_gpu_backward.py, forced-symbol replay) */
 } dcvc_dual_prior_args;
 
 /* GaussianEncoder.build_indexes (entropy_models.py:264-268) on a flat array, bit-exact through idx_edges. */

@@ -46,8 +46,12 @@ def small(a):
 
 
 def main():
+    """No argument: seq_1088x1920.npz (the default name-seeded weights, ~5 bpp: every latent busy, many values near a
+    rounding tie).  `w5`: seq_1088x1920_w5.npz — the SECOND weight set (seed 5, gain 1.2) whose P pictures code at a
+    realistic 0.3-0.4 bpp (round 4: the free-running GOP is asserted at 1e-4 at every depth on it)."""
     torch.set_num_threads(8)
-    d, i = build_nets()
+    w5 = len(sys.argv) > 1 and sys.argv[1] == "w5"
+    d, i = build_nets(seed=5, gain=1.2) if w5 else build_nets()
     dtap = Tap(d, ["optic_flow", "mv_decoder", "context_fusion_net", "contextual_decoder", "mv_hyper_prior_encoder",
                    "contextual_hyper_prior_encoder"])
     itap = Tap(i, ["hyper_enc"])
@@ -86,7 +90,7 @@ def main():
                     continue  # fp32 scale planes are 1 MB each; the smaller fixtures hold them for the index test
                 fx[p + k] = small(v)
             print(p, "bpp", float(r["bpp"]), "mse", float(r["mse"]), flush=True)
-    path = os.path.join(OUT, "seq_1088x1920.npz")
+    path = os.path.join(OUT, "seq_1088x1920_w5.npz" if w5 else "seq_1088x1920.npz")
     np.savez_compressed(path, **fx)
     print(path, os.path.getsize(path) / 1e6, "MB")
 

@@ -6,7 +6,8 @@ only ref_frame), the second with the full (detached) DPB -- the reference's `sin
 recursion (core/model/dcvc_hem.py:189-196).  Stored: the uniform draws add_noise made (so that
 a checker can replay them), every scalar output, the loss and, per parameter, the gradient's
 L2 norm and its first 8 values, the ten largest gradients in full (unit vectors, fp16); gradients of the per-sample
-q-scales in full.
+q-scales in full; since round 4 also the integers the reference's roundings produced (hyper latents, dual-prior
+residuals) for forced-symbol replay.
 
 train_256_b4 is BASELINE configs[2]'s shape: batch 4 of 256x256 pictures, one rate point per sample (the
 model's first four q-scales, lambdas 85 / 170 / 380 / 840 as core/config/defaults.py).
@@ -56,6 +57,21 @@ def main(N=2, size=64, out_name="train_64", lambdas=None):
         return out
 
     net.add_noise = add_noise
+    # round 4 (forced-symbol replay): the integers the reference's roundings produced in this very forward -- the two
+    # rounded hyper latents (quant(), video_model.py:488,514) and the rounded dual-prior residuals y_q
+    # (forward_dual_prior's second result, :499,526) -- so that a checker can feed them to its own forward and compare
+    # gradients without a value that sits on a rounding tie falling the other way
+    rounded = {}
+    net.mv_hyper_prior_encoder.register_forward_hook(lambda m, i, o: rounded.__setitem__("mv_z", torch.round(o.detach())))
+    net.contextual_hyper_prior_encoder.register_forward_hook(lambda m, i, o: rounded.__setitem__("z", torch.round(o.detach())))
+    orig_dual = net.forward_dual_prior
+
+    def dual(y, means, scales, qs, prior, write=False):
+        res = orig_dual(y, means, scales, qs, prior, write=write)
+        rounded["mv" if prior is net.mv_y_spatial_prior else "y"] = res[1].detach().clone()
+        return res
+
+    net.forward_dual_prior = dual
     fx = {"meta": np.array([N, size, LAMBDA, ME_WEIGHT], np.float64), "names": np.array(list(dmc_spec().keys())),
           "lambdas": lam.numpy().astype(np.float64), "q_mv": q_mv.reshape(-1).numpy().astype(np.float64),
           "q_y": q_y.reshape(-1).numpy().astype(np.float64)}
@@ -74,6 +90,10 @@ def main(N=2, size=64, out_name="train_64", lambdas=None):
         for key in ("bpp_y", "bpp_z", "bpp_mv_y", "bpp_mv_z", "bpp", "mse", "me_mse"):
             fx[p + key] = out[key].detach().numpy().astype(np.float64)
         fx[p + "loss"] = np.float64(loss.item())
+        for key, t in rounded.items():
+            a = t.numpy()
+            assert np.array_equal(a, np.rint(a)) and np.abs(a).max() < 32768, key
+            fx[p + "rounded_" + key] = a.astype(np.int8 if np.abs(a).max() < 128 else np.int16)
         fx[p + "dq_mv"] = qm.grad.numpy().astype(np.float64)
         fx[p + "dq_y"] = qy.grad.numpy().astype(np.float64)
         norms, heads = [], []

@@ -87,3 +87,44 @@ def test_dominant_kernel_keeps_its_occupancy_and_does_not_spill():
     assert len(res) > 50
     worst = max(res.items(), key=lambda kv: kv[1]["vgpr_spill_count"])
     assert worst[1]["vgpr_spill_count"] <= 16, worst
+
+
+def _k32_args(H, W, cs=64, ps=0, cout=64):
+    """Arguments that pass every check of dcvc_conv2d_k32 except possibly the picture-size limits; the pointers are
+    aligned dummies -- a refused call returns before anything is launched or dereferenced."""
+    from vcm_ts_amd import lib
+
+    a = lib.ConvArgs()
+    a.nseg, a.N, a.Hin, a.Win = 1, 1, H, W
+    a.seg[0].ptr, a.seg[0].C, a.seg[0].cs = 0x1000, 32, cs
+    a.wpack, a.bpack, a.out = 0x2000, 0x3000, 0x4000
+    a.ks, a.stride, a.Cout, a.Cout_pad, a.out_cs = 3, 1, cout, 64, 64
+    a.pixel_shuffle, a.precision = ps, lib.PRECISIONS["fp16x3"]
+    return a
+
+
+def test_conv_k32_refuses_pictures_beyond_its_24_bit_address_arithmetic():
+    """the kernel multiplies pixel index by channel stride with 24-bit multiplies (conv_k32.hip load_patch /
+    out_off); a 6144x3456 picture passes the 4 GiB checks at 32..63 channels and used to be addressed wrongly.  The
+    entry point now refuses (DCVC_E_ARG, callers fall back to dcvc_conv2d).  Host-only: a refused call launches nothing."""
+    import ctypes as C
+
+    from vcm_ts_amd import lib
+
+    L = lib.hip()
+    E_ARG = -1
+    assert L.dcvc_conv2d_k32(C.byref(_k32_args(3456, 6144, cs=32)), None) == E_ARG        # 21.2 M pixels, 2.7 GB image
+    assert L.dcvc_conv2d_k32(C.byref(_k32_args(4096, 4096, cs=32)), None) == E_ARG        # exactly 2^24 pixels
+    assert L.dcvc_conv2d_k32(C.byref(_k32_args(2048, 2048 + 64, cs=64, ps=1)), None) == E_ARG  # 4 x 4.3 M after the shuffle
+    assert L.dcvc_conv2d_k32(C.byref(_k32_args(64, 64, cs=1 << 22)), None) == E_ARG        # channel stride in bytes >= 2^24
+    assert L.dcvc_conv_k32_set_waves(6) == E_ARG
+    assert L.dcvc_conv_k32_set_waves(8) == 0
+
+
+def test_engine_routing_ignores_stray_environment(monkeypatch):
+    """Which kernel serves a layer is part of the arithmetic: the developer switches are honoured only with DCVC_DEV=1."""
+    src = open(os.path.join(ROOT, "vcm_ts_amd", "engine.py")).read()
+    for name in ("DCVC_SMALL", "DCVC_K32", "DCVC_PAIR_TAPS", "DCVC_K32_SIZES"):
+        assert f'sw("{name}"' in src and f'os.environ.get("{name}"' not in src, name
+    k32 = open(os.path.join(CSRC, "conv_k32.hip")).read()
+    assert "getenv" not in k32

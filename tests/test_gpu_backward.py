@@ -123,16 +123,27 @@ def test_frame_gradients_match_oracle_autograd(precision):
     assert G.frame_case(size=64, N=2, second=True, verbose=False, precision=precision) < 2e-3
 
 
+@pytest.mark.parametrize("forced", [False, True], ids=["free", "forced-symbols"])
+@pytest.mark.parametrize("precision", ["fp32", "fp16x3"])
 @pytest.mark.parametrize("name", ["train_64", "train_256_b4"])
-def test_frame_gradients_match_reference_fixture(name):
+def test_frame_gradients_match_reference_fixture(name, precision, forced):
     """HIP path against the numbers the reference itself produced (loss, bpp/mse, every parameter's gradient
     norm and first values, q-scale gradients): a 64x64 batch-2 clip and BASELINE configs[2]'s shape, batch 4 of
-    256x256 with one rate point / lambda per sample."""
+    256x256 with one rate point / lambda per sample.
+
+    precision (round 4): also in the arithmetic `bench.py --workload train` runs (fp16x3 forward /
+    data gradients, bf16x3 weight gradients), not only in exact fp32.
+    forced-symbols (round 4): the reference's OWN rounded integers of this forward (train_*.npz `rounded_*`, stored
+    by make_golden_train.py) replace this implementation's roundings (DMC._forced, dcvc_dual_prior_args.forced_q), so
+    no value on a rounding tie can fall the other way: what is left is pure float deviation, and the tensors that
+    carry < 1 % of the gradient -- judged at 15 % free-running because a handful of flipped symbols moves them by
+    several per cent -- are held to 2 %."""
     from tests.util import golden
     from vcm_ts_amd.dmc import DMC
     from vcm_ts_amd.synthetic import frames
 
     fx, fx_name = golden(name), name
+    fast = precision != "fp32"
     # every parameter's gradient norm: 5e-3 at 64x64 (round 1 allowed 2e-2; measured worst 2.2e-3).  The batch-4
     # 256x256 step has 64x the latent positions: the small gradients that reach the hyper-prior encoders and
     # SpyNet's coarse levels only through rounded symbols move by up to 3 % when a handful of ties fall the other
@@ -140,7 +151,7 @@ def test_frame_gradients_match_reference_fixture(name):
     per_tensor = {"train_64": 5e-3, "train_256_b4": 5e-2}[name]
     N, size, me_w = int(fx["meta"][0]), int(fx["meta"][1]), float(fx["meta"][3])
     dev = torch.device("cuda:0")
-    m = DMC(precision="fp32").to(dev).train()
+    m = DMC(precision=precision).to(dev).train()
     for p in m.parameters():
         p.requires_grad_(True)
     fr = frames(3, N * 3, size, size)
@@ -153,6 +164,8 @@ def test_frame_gradients_match_reference_fixture(name):
     for step, x in enumerate((x1, x2)):
         p = f"s{step}_"
         m._noise_override = {k: torch.from_numpy(fx[p + "noise_" + k]) for k in ("y", "mv_y", "z", "mv_z")}
+        if forced:
+            m._forced = {k: torch.from_numpy(fx[p + "rounded_" + k].astype(np.float32)) for k in ("mv_z", "z", "mv", "y")}
         m.zero_grad(set_to_none=True)
         qm, qy = q_mv.clone().requires_grad_(), q_y.clone().requires_grad_()
         out = m.forward_one_frame(x, dpb, qm, qy)
@@ -188,7 +201,9 @@ def test_frame_gradients_match_reference_fixture(name):
             # after one more tie of the motion-vector prior fell the other way when the library was rebuilt without
             # packed-FP32 instructions; the tensors with >= 1 % stay at 5e-3)
             minor = want < 1e-2 * total_norm
-            tol_t = ({"train_64": 2e-2}.get(fx_name, 0.15)) if minor else per_tensor
+            tol_t = ((2e-2 if forced else {"train_64": 2e-2}.get(fx_name, 0.15)) if minor else per_tensor)
+            if fast and not forced:  # the split-precision forward moves a few more ties than the exact one
+                tol_t = max(tol_t, 5e-2 if minor else tol_t)
             assert abs(got - want) <= tol_t * want + 1e-8, (name, got, want)
             head = g.reshape(-1)[:8].cpu().numpy()
             np.testing.assert_allclose(head, fx[p + "grad_head"][i][: head.size], rtol=0, atol=2 * tol_t * want + 1e-8,
@@ -197,7 +212,7 @@ def test_frame_gradients_match_reference_fixture(name):
             sq_diff += (got - want) ** 2
             if want > 1e-6 and abs(got - want) / want > worst[1]:
                 worst = (name, abs(got - want) / want)
-        print(f"\n[{fx_name} step {step}] gradient norms vs the reference: whole {sq_diff ** 0.5 / sq_ref ** 0.5:.2e}, "
+        print(f"\n[{fx_name} {precision} {'forced' if forced else 'free'} step {step}] gradient norms vs the reference: whole {sq_diff ** 0.5 / sq_ref ** 0.5:.2e}, "
               f"worst tensor {worst[0]} {worst[1]:.2e}")
         assert sq_diff ** 0.5 <= 2e-3 * sq_ref ** 0.5
         # directions (round 3): the ten tensors with the largest gradients are stored in full (unit vectors); the norms
@@ -213,6 +228,7 @@ def test_frame_gradients_match_reference_fixture(name):
         assert cos_worst[1] >= 0.9999, cos_worst
         dpb = {k: v.detach() for k, v in out["dpb"].items()}
     m._noise_override = None
+    m._forced = None
 
 
 def test_frozen_parameters_get_no_gradient_and_dpb_inputs_get_one():
@@ -286,6 +302,7 @@ def test_training_step_is_bit_reproducible(N, size):
             for k in ga:
                 assert torch.equal(ga[k], gb[k]), k
     m._noise_override = None
+    m._forced = None
 
 
 def test_batch_pack_plan_equals_per_layer_packing():

@@ -265,6 +265,189 @@ def test_bench_size_gop8_curve_against_reference(nets):
     torch.cuda.empty_cache()
 
 
+class _ForcedSymbols:
+    """Teacher forcing: the decoder networks of `codec` are fed the REFERENCE's integer planes of picture `prefix`
+    (tests/golden/seq_1088x1920*.npz hold every plane of every picture) in bitstream order instead of what a range
+    decoder would return.  DPB_t is a function of (DPB_{t-1}, symbols of picture t) through float networks only -- no
+    rounding in between -- so the forced decoder's DPB tracks the reference's DPB to float accuracy at every depth,
+    without the cascade of rounding ties a free-running encoder accumulates."""
+
+    def __init__(self, codec, fx, prefix, scale_tags):
+        self.codec, self.fx, self.prefix, self.tags = codec, fx, prefix, list(scale_tags)
+
+    def _plane(self, key):
+        return torch.from_numpy(self.fx[self.prefix + key].astype(np.int32).reshape(-1)).to(self.codec.device)
+
+    def __enter__(self):
+        c = self.codec
+        c._decode_factorized = lambda name, N, C_, H, W: self._plane("sym_mv_z" if name.endswith("_mv") else "sym_z")
+        c._decode_scale = lambda idx: self._plane("sym_" + self.tags.pop(0))
+        c._clamp_decoded = False  # the fixture's DPB recursion is forward_one_frame's: unclamped (video_model.py:535)
+        return self
+
+    def __exit__(self, *exc):
+        for k in ("_decode_factorized", "_decode_scale", "_clamp_decoded"):
+            self.codec.__dict__.pop(k, None)
+        assert not self.tags or exc[0] is not None, self.tags
+
+
+def _weights_for(fixture, d, i):
+    if fixture.endswith("_w5"):
+        d.load_state_dict(oracle_weights("dmc", 5, 1.2))
+        i.load_state_dict(oracle_weights("intra", 5, 1.2))
+        d.update(force=True)
+        i.update(force=True)
+
+
+def _codecs(precision):
+    from vcm_ts_amd.dmc import DMC
+    from vcm_ts_amd.intra import IntraNoAR
+
+    dev = torch.device("cuda:0")
+    d, i = DMC(precision=precision).to(dev).eval(), IntraNoAR(precision=precision).to(dev).eval()
+    d.update()
+    i.update()
+    return d, i
+
+
+_SCALARS = ("bpp_mv_y", "bpp_mv_z", "bpp_y", "bpp_z", "bpp", "me_mse", "mse", "bit", "bit_y", "bit_z", "bit_mv_y", "bit_mv_z")
+
+
+def _scalar_devs(r, fx, p):
+    devs = {}
+    for k in _SCALARS:
+        got = float(r[k].reshape(-1)[0]) if torch.is_tensor(r[k]) else float(r[k])
+        want = float(np.asarray(fx[p + k]).reshape(-1)[0])
+        devs[k] = abs(got - want) / abs(want)
+    psnr_ref = 10 * np.log10(1.0 / float(fx[p + "mse"][0]))
+    devs["psnr"] = abs(10 * np.log10(1.0 / r["mse"].item()) - psnr_ref) / max(abs(psnr_ref), 1.0)
+    return devs
+
+
+@pytest.mark.parametrize("fixture", ["seq_1088x1920", "seq_1088x1920_w5"])
+@pytest.mark.parametrize("precision", ["fp32", "fp16x3"])
+def test_bench_size_teacher_forced_every_depth(precision, fixture):
+    """Per-picture parity at BASELINE configs[1]'s size at EVERY depth of the reference's I + 7 P run, free of the GOP
+    recursion.  For t = 1..7 the encoder is given the reference's own DPB_{t-1} -- rebuilt on the
+    GPU by the decoder networks from the reference's symbol planes (_ForcedSymbols), and checked against the
+    reference's DPB statistics and crops -- and every rate / distortion scalar of picture t is compared with the
+    reference's p{t}_* at north_star's 1e-4, in BOTH arithmetic modes; integer planes are counted against the
+    reference's with the hinge bound of _check_sequence (each picture now only sees its own ties)."""
+    from vcm_ts_amd.pipeline import pad_frame
+
+    d, i = _codecs(precision)
+    _weights_for(fixture, d, i)
+    fx = golden(fixture)
+    n_p = max(int(k[1]) for k in fx.files if k.startswith("p") and k[1].isdigit() and k.endswith("_bpp"))
+    fr = frames(int(fx["seed"]), n_p + 1, int(fx["height"]), int(fx["width"]))
+    xs = [pad_frame(torch.from_numpy(fr[t : t + 1])).cuda() for t in range(n_p + 1)]
+    h, w = int(fx["height"]), int(fx["width"])
+    dummy = bytes(16)
+    with _ForcedSymbols(i, fx, "i_", ["y0", "y1"]):
+        x_hat = i.decompress(dummy, h, w, 1.0, coder="host")["x_hat"].clone()
+    np.testing.assert_allclose(x_hat[..., 512:576, 960:1024].cpu().numpy(), fx["i_xhat_mid"], atol=1e-5)
+    np.testing.assert_allclose(stats(x_hat)[:2], fx["i_xhat_stats"][:2], rtol=1e-5)
+    dpb = {"ref_frame": x_hat, "ref_feature": None, "ref_y": None, "ref_mv_y": None}
+    lines = [f"# {fixture} {precision}, teacher-forced: picture, worst relative deviation of a total (bpp/bit/mse/PSNR), of a component, differing symbols motion / residual"]
+    worst = 0.0
+    for t in range(1, n_p + 1):
+        p = f"p{t}_"
+        v = d.compress(xs[t], dpb, 1.0, 1.0)["_views"]
+        report = {}
+        _plane_report({"sym_mv_z": v["sym_mv_z"], "sym_mv_y0": v["r_mv"]["sym"][0], "sym_mv_y1": v["r_mv"]["sym"][1],
+                       "idx_mv_y0": v["r_mv"]["idx"][0], "idx_mv_y1": v["r_mv"]["idx"][1], "sym_z": v["sym_z"],
+                       "sym_y0": v["r_y"]["sym"][0], "sym_y1": v["r_y"]["sym"][1], "idx_y0": v["r_y"]["idx"][0],
+                       "idx_y1": v["r_y"]["idx"][1]}, fx, p, report)
+        r = d.forward_one_frame(xs[t], dpb, 1.0, 1.0)
+        devs = _scalar_devs(r, fx, p)
+        tot = max(devs[k] for k in ("bpp", "bit", "mse", "psnr"))
+        comp = max(devs.values())
+        mv = sum(report[p + f"sym_mv_y{k}"][0] for k in (0, 1)) / sum(report[p + f"sym_mv_y{k}"][1] for k in (0, 1))
+        yy = sum(report[p + f"sym_y{k}"][0] for k in (0, 1)) / sum(report[p + f"sym_y{k}"][1] for k in (0, 1))
+        lines.append(f"P{t}: totals {tot:.1e}  components {comp:.1e}   symbols: motion {mv:.2e}  residual {yy:.2e}  "
+                     f"max |delta| {max(x[2] for x in report.values())}")
+        # north_star's tolerance, at every depth, on the totals AND on every component, in both modes
+        for k, dv in devs.items():
+            assert dv <= TOL, (fixture, precision, p + k, dv)
+        worst = max(worst, comp)
+        # planes: every symbol delta is one step; motion planes within the hinge bound (they only see DPB_{t-1})
+        for k, (bad, n, mx) in report.items():
+            if "_sym_" in k:
+                assert mx <= 1, (k, mx)
+            if "_mv_" in k:
+                assert bad <= max(2, int(5e-3 * n)) + (49 * 32 * report[p + "sym_mv_y0"][0] if k.endswith("1") else 0), (k, bad, n)
+            assert bad <= max(2, int(0.03 * n)), (k, bad, n)
+        # the reference's DPB_t through the decoder networks, from the reference's symbols of picture t
+        with _ForcedSymbols(d, fx, p, ["mv_y0", "mv_y1", "y0", "y1"]):
+            nxt = d.decompress(dpb, dummy, h, w, 1.0, 1.0, coder="host")["dpb"]
+        nxt = {k: t_.clone() for k, t_ in nxt.items()}
+        for k, t_ in nxt.items():
+            want_mean, want_std, want_max = fx[p + k + "_stats"][:3]
+            assert abs(stats(t_)[0] - want_mean) <= 2e-5 * max(abs(want_mean), want_std), (p + k, stats(t_)[0], want_mean)
+            np.testing.assert_allclose(stats(t_)[1], want_std, rtol=2e-5, err_msg=p + k)
+            np.testing.assert_allclose(stats(t_)[2], want_max, rtol=1e-4, err_msg=p + k)
+            np.testing.assert_allclose(t_[..., :8, :8].cpu().numpy(), fx[p + k + "_crop"], rtol=2e-4, atol=2e-5, err_msg=p + k)
+        # (float noise of ~50 layers between two summation orders: 6e-5 absolute on values of +-1.3 measured)
+        np.testing.assert_allclose(nxt["ref_frame"][..., 512:576, 960:1024].cpu().numpy(), fx[p + "recon_mid"], rtol=2e-4, atol=2e-4)
+        dpb = nxt
+    print("\n" + "\n".join(lines))
+    out = os.environ.get("DCVC_CURVE_OUT")
+    if out:
+        with open(out, "a") as f:
+            f.write("\n".join(lines) + "\n")
+    d.engine().release()
+    i.engine().release()
+    torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("precision", ["fp32", "fp16x3"])
+def test_bench_size_low_rate_gop8_free_running(precision):
+    """tests/golden/seq_1088x1920_w5.npz (round 4): the reference's I + 7 P run at 1088x1920 with the SECOND weight set
+    (seed 5, gain 1.2: P pictures at 0.3-0.4 bpp, the rate range a trained model works at).  FREE-RUNNING (each
+    picture coded from this implementation's own DPB), every total within north_star's 1e-4 at every depth, both
+    arithmetic modes; symbol planes counted."""
+    from vcm_ts_amd.pipeline import pad_frame
+
+    d, i = _codecs(precision)
+    _weights_for("seq_1088x1920_w5", d, i)
+    fx = golden("seq_1088x1920_w5")
+    n_p = max(int(k[1]) for k in fx.files if k.startswith("p") and k[1].isdigit() and k.endswith("_bpp"))
+    assert n_p >= 7
+    fr = frames(int(fx["seed"]), n_p + 1, int(fx["height"]), int(fx["width"]))
+    xs = [pad_frame(torch.from_numpy(fr[t : t + 1])).cuda() for t in range(n_p + 1)]
+    ri = i(xs[0], 1.0)
+    for k in ("mse", "bpp", "bpp_y", "bpp_z"):
+        _close(ri[k], fx[f"i_{k}"], msg="i_" + k)
+    dpb = {"ref_frame": ri["x_hat"], "ref_feature": None, "ref_y": None, "ref_mv_y": None}
+    lines = [f"# seq_1088x1920_w5 {precision}, free-running: picture, worst relative deviation of a total, of a component, differing symbols motion / residual"]
+    for t in range(1, n_p + 1):
+        p = f"p{t}_"
+        v = d.compress(xs[t], dpb, 1.0, 1.0)["_views"]
+        report = {}
+        _plane_report({"sym_mv_y0": v["r_mv"]["sym"][0], "sym_mv_y1": v["r_mv"]["sym"][1], "sym_y0": v["r_y"]["sym"][0],
+                       "sym_y1": v["r_y"]["sym"][1]}, fx, p, report)
+        r = d.forward_one_frame(xs[t], dpb, 1.0, 1.0)
+        dpb = r["dpb"]
+        devs = _scalar_devs(r, fx, p)
+        tot = max(devs[k] for k in ("bpp", "bit", "mse", "psnr"))
+        mv = sum(report[p + f"sym_mv_y{k}"][0] for k in (0, 1)) / sum(report[p + f"sym_mv_y{k}"][1] for k in (0, 1))
+        yy = sum(report[p + f"sym_y{k}"][0] for k in (0, 1)) / sum(report[p + f"sym_y{k}"][1] for k in (0, 1))
+        lines.append(f"P{t}: totals {tot:.1e}  components {max(devs.values()):.1e}   symbols: motion {mv:.2e}  residual {yy:.2e}  "
+                     f"max |delta| {max(x[2] for x in report.values())}")
+        for k in ("bpp", "bit", "mse", "psnr"):
+            assert devs[k] <= TOL, (precision, p + k, devs[k])
+        for k, dv in devs.items():
+            assert dv <= 5e-4, (precision, p + k, dv)
+    print("\n" + "\n".join(lines))
+    out = os.environ.get("DCVC_CURVE_OUT")
+    if out:
+        with open(out, "a") as f:
+            f.write("\n".join(lines) + "\n")
+    d.engine().release()
+    i.engine().release()
+    torch.cuda.empty_cache()
+
+
 def test_batch_of_rate_points_matches_reference(nets):
     d, i = nets
     fx = golden("seq_64_b2")
@@ -461,6 +644,68 @@ def test_folder_encode_decode_round_trip(tmp_path):
         a = np.asarray(Image.open(os.path.join(rec_d, f"im{t + 1:05d}.png")))
         b = np.asarray(Image.open(os.path.join(rec_d2, f"im{t + 1:05d}.png")))
         assert np.array_equal(a, b)
+
+
+def test_folder_encode_with_two_gop_streams_writes_the_same_files(tmp_path):
+    """run_codec.encode_folder(gop_streams=2): two GOPs of the folder in flight on the GPU (ConcurrentGopEncoder, one
+    shared pool of PNG-decoding threads).  8 pictures at GOP 3 = GOPs 0 and 2 on stream 0 (the last
+    one partial), GOP 1 on stream 1: every .bin file, the bits list and the encoder-side reconstructions are identical
+    to the one-stream loop's, with reader threads and inline."""
+    from PIL import Image
+
+    from vcm_ts_amd import run_codec
+
+    src = os.path.join(tmp_path, "src")
+    os.makedirs(src)
+    fr = frames(22, 8, 100, 150)
+    for t in range(8):
+        Image.fromarray(np.clip(np.rint(fr[t].transpose(1, 2, 0) * 255), 0, 255).astype(np.uint8)).save(
+            os.path.join(src, f"im{t + 1:05d}.png"))
+    out = {}
+    for tag, kw in (("one", dict(gop_streams=1)), ("two", dict(gop_streams=2)), ("two_inline", dict(gop_streams=2, io_workers=0)),
+                    ("three", dict(gop_streams=3, io_workers=2))):
+        bins, rec = os.path.join(tmp_path, "bins_" + tag), os.path.join(tmp_path, "rec_" + tag)
+        bits, size = run_codec.encode_folder(src, bins, rec, gop=3, q=(1.0, 1.1, 0.9), precision="fp16x3", **kw)
+        assert size == (100, 150) and len(bits) == 8
+        names = sorted(os.listdir(bins))
+        assert names == [f"im{t + 1:05d}.bin" for t in range(8)]
+        out[tag] = (bits, [open(os.path.join(bins, n), "rb").read() for n in names],
+                    [np.asarray(Image.open(os.path.join(rec, f"im{t + 1:05d}.png"))) for t in range(8)])
+    for tag in ("two", "two_inline", "three"):
+        assert out[tag][0] == out["one"][0], tag
+        assert out[tag][1] == out["one"][1], tag
+        assert all(np.array_equal(a, b) for a, b in zip(out[tag][2], out["one"][2])), tag
+    assert run_codec.decode_folder(os.path.join(tmp_path, "bins_two"), os.path.join(tmp_path, "dec"), 100, 150, gop=3,
+                                   precision="fp16x3") == 8
+    for t in range(8):
+        assert np.array_equal(np.asarray(Image.open(os.path.join(tmp_path, "dec", f"im{t + 1:05d}.png"))), out["one"][2][t])
+
+
+def test_folder_encode_fails_loudly_when_the_split_fp16_range_is_exceeded(tmp_path):
+    """the fast mode clamps |activation| > 8188 on load and only FLAGS it (status word); the shipped folder
+    loop now reads that flag once per GOP.  A checkpoint with an absurd bias (outputs ~1e4) must make encode_folder
+    raise instead of writing .bin files and reporting success; the same checkpoint codes fine in exact-fp32 mode."""
+    from PIL import Image
+
+    from vcm_ts_amd import lib, run_codec
+
+    src = os.path.join(tmp_path, "src")
+    os.makedirs(src)
+    fr = frames(23, 4, 64, 64)
+    for t in range(4):
+        Image.fromarray(np.clip(np.rint(fr[t].transpose(1, 2, 0) * 255), 0, 255).astype(np.uint8)).save(
+            os.path.join(src, f"im{t + 1:05d}.png"))
+    for precision, fails in (("fp16x3", True), ("fp32", False)):
+        i_net, p_net = run_codec._nets(torch.device("cuda:0"), precision)
+        with torch.no_grad():
+            p_net.P("feature_extractor.conv1.bias").fill_(1.0e4)
+        bins = os.path.join(tmp_path, "bins_" + precision)
+        if fails:
+            with pytest.raises(lib.KernelError, match="range"):
+                run_codec.encode_folder(src, bins, None, gop=4, nets=(i_net, p_net))
+        else:
+            bits, _ = run_codec.encode_folder(src, bins, None, gop=4, nets=(i_net, p_net))
+            assert len(bits) == 4
 
 
 def test_batch_of_rate_points_compress(nets):

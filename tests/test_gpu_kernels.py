@@ -570,6 +570,42 @@ def test_fused_se_squeeze_matches_mean_of_the_output(eng, eng_split, cout, H, W,
         torch.testing.assert_close(gate_fused, gate_sep, rtol=1e-5, atol=1e-6)
 
 
+def test_k32_wave_count_changes_no_bit(eng_split):
+    """conv_k32's 64-channel 3x3 kernel as 4- and as 8-wave workgroups (dcvc_conv_k32_set_waves): output, residual path
+    AND the fused SELayer channel sums are bit-identical -- the sums inside a tile are ordered by tile row, not by the
+    wave that owns the row (the two builds used to differ in the last bit of the SE gate, which made the
+    codec's deviation from the reference depend on a tuning knob)."""
+    from vcm_ts_amd import lib
+
+    e = eng_split
+    g = torch.Generator().manual_seed(77)
+    N, cin, cout, H, W = 2, 64, 64, 45, 75  # ragged tiles in both directions
+    x = torch.randn(N, cin, H, W, generator=g)
+    r = torch.randn(N, cout, H, W, generator=g)
+    w = torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(cin * 9)
+    b = torch.randn(cout, generator=g)
+    pk = e.pack(("waves", cout), torch.nn.Parameter(w.cuda()), torch.nn.Parameter(b.cuda()), (cin,), False)
+    xin, res = to_view(e, "wv/in", x), to_view(e, "wv/res", r)
+    out = e.buf("wv/out", N, H, W, cout)
+    buf, parts = e.chan_partial_buf("wv", pk, out, 1)
+    e.k32_everywhere = True
+    got = {}
+    try:
+        assert e.k32_capable(pk, 1, out, res, None, None, [xin])
+        for waves in (4, 8):
+            lib.check(e.L.dcvc_conv_k32_set_waves(waves), "set_waves")
+            buf.fill_(float("nan"))
+            out.base.fill_(float("nan"))
+            e.conv(pk, [xin], out, res=res, out_slope=0.1, chan_partial=buf)
+            got[waves] = (out.base.clone(), buf.clone())
+    finally:
+        e.L.dcvc_conv_k32_set_waves(8)
+        e.k32_everywhere = False
+    assert torch.equal(got[4][0], got[8][0])
+    assert torch.equal(got[4][1][: N * parts * pk.Cout_pad], got[8][1][: N * parts * pk.Cout_pad])
+    assert torch.isfinite(got[8][1][: N * parts * pk.Cout_pad]).all()
+
+
 def test_build_indexes_bit_exact_against_reference_planes(eng):
     """GaussianEncoder.build_indexes (entropy_models.py:264-268) on the device, integer-equal to what
     the REFERENCE produced: its sweep over bin edges / zeros / negatives (tables.npz) and the index

@@ -85,6 +85,29 @@ def test_bench_runs_with_world_size_two():
     assert {"roofline", "metric", "unit", "ms_per_step", "config"} <= set(d)
 
 
+def test_bench_two_ranks_two_gop_streams_match_the_one_rank_run():
+    """the driver's N > 1 form rehearsed as far as one GPU allows -- `bench.py --gpus 2
+    --dist-backend gloo`, two ranks x two GOP streams each on the one card (four GOPs in flight: the per-GPU structure
+    of the 8-GPU run) -- must join both ranks in the collective and code rank 0's first GOP into exactly the bytes the
+    one-rank run produces (GOPs are independent: sharding changes nothing a decoder sees)."""
+    base = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0", "--height", "256", "--width", "384",
+            "--gop", "4", "--gop-streams", "2", "--no-cpu-baseline", "--no-parity-leg", "--no-extra-workloads"]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    lines = {}
+    for n in (1, 2):
+        r = subprocess.run(base + ["--gpus", str(n), "--dist-backend", "gloo"], env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines[n] = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    one, two = lines[1], lines[2]
+    assert two["n_gpus"] == 2 and two["config"]["collective_ranks"] == 2 and len(two["config"]["per_rank_frames_per_s"]) == 2
+    assert two["config"]["gops_per_step_per_gpu"] == 2
+    assert two["config"]["payload_sha16_gop0"] == one["config"]["payload_sha16_gop0"]
+    assert two["config"]["bits_per_gop"] > 0 and two["config"]["fp16x3_range_status"] == 0
+    for d in (one, two):
+        c = d["config"]
+        assert c["host_cpu_s_per_frame"] > 0 and c["host_threads"] >= 1 and c["hbm_bytes_reserved"] >= c["hbm_bytes_workspaces"] > 0
+
+
 def test_bench_launches_its_own_ranks():
     """`python bench.py --gpus 2` by itself (no torchrun around it, the form the driver uses): the parent starts
     one rank per GPU as a child torch.distributed.run before touching the GPU and hands back its exit code; a

@@ -97,3 +97,27 @@ def test_prefetching_png_reader_returns_the_frames_of_the_sequential_reader(tmp_
             np.testing.assert_array_equal(a, u8_to_unit_float(torch.from_numpy(u)).numpy()[0])
     every = np.arange(256, dtype=np.uint8).reshape(16, 16, 1).repeat(3, axis=2)
     np.testing.assert_array_equal(u8_to_unit_float(torch.from_numpy(every)).numpy()[0], every.astype("float32").transpose(2, 0, 1) / 255.0)
+
+
+def test_png_writer_pool_propagates_failures_and_bounds_its_queue(tmp_path):
+    """run_codec.PNGWriters: a failed PNG write surfaces in the caller instead of vanishing with its
+    future, at most 2 x workers pictures wait in memory, workers = 0 writes inline."""
+    import numpy as np
+    import pytest
+
+    from vcm_ts_amd.run_codec import PNGWriters
+
+    a = np.zeros((8, 8, 3), np.float32)
+    with PNGWriters(2) as w:
+        for k in range(9):
+            w.submit(a, str(tmp_path / f"ok{k}.png"))
+            assert len(w.pending) <= 4
+    assert sorted(p.name for p in tmp_path.iterdir()) == [f"ok{k}.png" for k in range(9)]
+    with pytest.raises(OSError):
+        with PNGWriters(2) as w:
+            w.submit(a, str(tmp_path / "no_such_dir" / "x.png"))
+    with pytest.raises(OSError):
+        PNGWriters(0).submit(a, str(tmp_path / "no_such_dir" / "x.png"))  # inline
+    w0 = PNGWriters(0)
+    w0.submit(a, str(tmp_path / "inline.png"))
+    assert w0.pool is None and (tmp_path / "inline.png").exists()

@@ -107,7 +107,7 @@ __global__ __launch_bounds__(64 * NWAVE, NWAVE / 2) void conv_k32(const K32 a) {
     constexpr int PH = BH + KS - 1, PW = BW + KS - 1, PAD = KS / 2;
     constexpr int T = KS * KS, TPS = KS, NST = KS;  // one filter row of taps in LDS at a time
     constexpr int LDS_MAIN = PH * PW * REC + TPS * 8 * BN * 4;
-    static_assert(LDS_MAIN >= NWAVE * BN, "the SE reduction reuses the front of the buffer");
+    static_assert(LDS_MAIN >= 8 * BN, "the SE reduction reuses the front of the buffer");
     __shared__ __attribute__((aligned(16))) float lds[LDS_MAIN];
     float *patch = lds;
     float *wl = lds + PH * PW * REC;
@@ -379,11 +379,13 @@ __global__ __launch_bounds__(64 * NWAVE, NWAVE / 2) void conv_k32(const K32 a) {
                     rv[m][n] = ld16(res_b, ok ? out_off(m, n, a.res_cs) : 0u);
             }
     }
-    f32x4 csum[NTW];
+    // (fused SE squeeze) channel sums per ROW of the tile, so that the result does not depend on how many rows a wave owns
+    f32x4 csum[RW][NTW];
     float vmax = 0.f;  // largest |output| this lane stores (range guard)
 #pragma unroll
     for (int n = 0; n < NTW; ++n) {
-        csum[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < RW; ++r) csum[r][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
         const int ch = n0 + n * 16 + (lane >> 4) * 4;
         const f32x4 bias = *(const f32x4 *)&a.bpack[ch];  // (bpack is Cout_pad long)
         f32x4 gate = {1.f, 1.f, 1.f, 1.f};
@@ -420,7 +422,7 @@ __global__ __launch_bounds__(64 * NWAVE, NWAVE / 2) void conv_k32(const K32 a) {
                 else asm volatile("" ::"v"(v));
             } else if (ok) {
                 if (a.res2) v = ld16(res2_b, out_off(m, n, a.res2_cs)) + v;
-                if (a.chan_partial) csum[n] += v;
+                if (a.chan_partial) csum[m >> 1][n] += v;
                 vmax = fmaxf(vmax, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
                 if (!(K32_ABLATE & 4)) *(f32x4 *)(out_b + out_off(m, n, a.out_cs)) = v;
                 else asm volatile("" ::"v"(v));
@@ -430,26 +432,31 @@ __global__ __launch_bounds__(64 * NWAVE, NWAVE / 2) void conv_k32(const K32 a) {
     K32_STAMP(59);
     if (a.status && !(vmax <= ACT_LIMIT)) atomicOr(a.status, DCVC_STATUS_ACT_SATURATED);
     if (a.chan_partial) {
-        // SELayer's AdaptiveAvgPool (video_net.py:149-162) rides on the producing convolution: the 16 pixel lanes of a
-        // channel quad by a butterfly inside the wave, the four waves through LDS, one partial row per workgroup;
-        // dcvc_channel_mean_finish adds the rows in a fixed order (no atomics: encoder and decoder derive
-        // bit-identical gates)
+        // SELayer's AdaptiveAvgPool (video_net.py:149-162) rides on the producing convolution: per tile ROW the two
+        // 16-pixel halves, then the 16 pixel lanes of a channel quad by a butterfly inside the wave, the 8 rows through
+        // LDS in row order, one partial row per workgroup; dcvc_channel_mean_finish adds those in a fixed order (no
+        // atomics: encoder and decoder derive bit-identical gates).  The order is a property of the TILE, not of the
+        // number of waves that share it (round 4, ADVICE r03: the 4- and the 8-wave build used to differ in the last bit)
 #pragma unroll
-        for (int n = 0; n < NTW; ++n)
+        for (int r = 0; r < RW; ++r)
 #pragma unroll
-            for (int off = 1; off < 16; off <<= 1)
+            for (int n = 0; n < NTW; ++n)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) csum[n][e] += __shfl_xor(csum[n][e], off);
+                for (int off = 1; off < 16; off <<= 1)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) csum[r][n][e] += __shfl_xor(csum[r][n][e], off);
         float *red = lds;
         __syncthreads();  // every wave is done with the main loop's LDS
         if ((lane & 15) == 0)
 #pragma unroll
-            for (int n = 0; n < NTW; ++n) *(f32x4 *)&red[wave * BN + n * 16 + (lane >> 4) * 4] = csum[n];
+            for (int r = 0; r < RW; ++r)
+#pragma unroll
+                for (int n = 0; n < NTW; ++n) *(f32x4 *)&red[(wave * RW + r) * BN + n * 16 + (lane >> 4) * 4] = csum[r][n];
         __syncthreads();
         if (tid < BN && n0 + tid < a.Cout_pad) {
             float s = red[tid];
 #pragma unroll
-            for (int w = 1; w < NWAVE; ++w) s += red[w * BN + tid];  // fixed order
+            for (int w = 1; w < BH; ++w) s += red[w * BN + tid];  // fixed order: tile rows 0..7
             const size_t part = (size_t)img * (a.nty * a.ntx) + (size_t)ty * a.ntx + tx;
             a.chan_partial[part * a.Cout_pad + n0 + tid] = s;
         }
@@ -467,6 +474,8 @@ int launch(K32 &k, int N, hipStream_t st) {
     hipLaunchKernelGGL((conv_k32<KS, NTW, NWAVE>), grid, dim3(64 * NWAVE), 0, st, k);
     return hipGetLastError() == hipSuccess ? DCVC_OK : DCVC_E_LAUNCH;
 }
+
+int g_k32_waves = 8;
 
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 inline bool aligned16(const void *p, int cs) { return p == nullptr || ((((uintptr_t)p) & 15) == 0 && (cs & 3) == 0); }
@@ -522,6 +531,12 @@ extern "C" int dcvc_conv_k32_pack_weights(const float *w, const float *b, int32_
     return clamped ? DCVC_E_RANGE : DCVC_OK;
 }
 
+extern "C" int dcvc_conv_k32_set_waves(int32_t waves) {
+    if (waves != 4 && waves != 8) return DCVC_E_ARG;
+    g_k32_waves = waves;
+    return DCVC_OK;
+}
+
 extern "C" int dcvc_conv2d_k32(const dcvc_conv_args *a, void *stream) {
     if (!a || a->nseg < 1 || a->nseg > DCVC_MAX_SEG || !a->out || !a->wpack || !a->bpack) return DCVC_E_ARG;
     if (a->stride != 1 || (a->ks != 1 && a->ks != 3) || a->precision != DCVC_PREC_FP16X3) return DCVC_E_ARG;
@@ -538,6 +553,14 @@ extern "C" int dcvc_conv2d_k32(const dcvc_conv_args *a, void *stream) {
     }
     {  // output / residual images are addressed with 32-bit byte offsets (and as raw buffers)
         const unsigned long long opix = (unsigned long long)a->Hin * a->Win * (a->pixel_shuffle ? 4 : 1);
+        // the kernel forms pixel index x channel stride with 24-bit multiplies (load_patch, out_off): both factors
+        // must stay below 2^24 -- a 6144x3456 picture (21 M pixels) passes the 4 GiB tests below with 32..63 channels
+        if (opix >= (1ull << 24) || (unsigned long long)a->out_cs * 4ull >= (1ull << 24) ||
+            (a->res && (unsigned long long)a->res_cs * 4ull >= (1ull << 24)) ||
+            (a->res2 && (unsigned long long)a->res2_cs * 4ull >= (1ull << 24)))
+            return DCVC_E_ARG;
+        for (int s = 0; s < a->nseg; ++s)
+            if ((unsigned long long)a->seg[s].cs * 4ull >= (1ull << 24)) return DCVC_E_ARG;
         if (opix * a->out_cs * 4ull > 0xfffffff0ull || (a->res && opix * a->res_cs * 4ull > 0xfffffff0ull) ||
             (a->res2 && opix * a->res2_cs * 4ull > 0xfffffff0ull))
             return DCVC_E_ARG;
@@ -576,10 +599,10 @@ extern "C" int dcvc_conv2d_k32(const dcvc_conv_args *a, void *stream) {
     if (a->chan_partial && a->pixel_shuffle) return DCVC_E_ARG;
     hipStream_t st = (hipStream_t)stream;
     const bool wide = (a->Cout_pad % 64) == 0;
-    // the wide 3x3 kernel runs as 8-wave workgroups (four waves per SIMD with two resident workgroups); DCVC_K32_WAVES=4
-    // is the developer A/B switch back to 4 waves (same results either way; read per call)
-    const char *env = getenv("DCVC_K32_WAVES");
-    const bool w8 = !(env && atoi(env) == 4);
+    // the wide 3x3 kernel runs as 8-wave workgroups (four waves per SIMD with two resident workgroups);
+    // dcvc_conv_k32_set_waves(4) is the developer A/B switch back to 4 waves (bit-identical results: the sums inside a
+    // tile are ordered by tile row, not by wave -- tests/test_gpu_kernels.py)
+    const bool w8 = g_k32_waves != 4;
     if (a->ks == 3) return wide ? (w8 ? launch<3, 4, 8>(k, a->N, st) : launch<3, 4, 4>(k, a->N, st)) : launch<3, 2, 4>(k, a->N, st);
     return wide ? launch<1, 4, 4>(k, a->N, st) : launch<1, 2, 4>(k, a->N, st);
 }

@@ -243,7 +243,7 @@ __global__ void dual_prior_kernel(const dcvc_dual_prior_args a, int64_t total) {
         if (MODE == 0) {
             const float yq = a.y[pix * a.y_cs + c] / qs;
             const float res = yq - mu;
-            q = rintf(res);
+            q = a.forced_q ? a.forced_q[e] : rintf(res);
             if (a.y_res) a.y_res[e] = res;
             if (a.y_q) a.y_q[e] = q;
             if (a.scales_hat) a.scales_hat[e] = sc;

@@ -95,6 +95,14 @@ class CodecBase(nn.Module):
     """What DMC and IntraNoAR share: parameter tree, engine, q-scale plumbing, tables."""
 
     _tag = "codec"
+    # decompress() clamps the reconstruction to [0, 1] as the reference's does (video_model.py:413, image_model.py:199).
+    # tests/test_gpu_codec.py's teacher-forced parity check sets False to follow the reference's ESTIMATE-path DPB
+    # recursion (forward_one_frame keeps the unclamped picture, video_model.py:535) through the decoder networks
+    _clamp_decoded = True
+    # tests: {"mv_z", "z", "mv", "y"} -> integer-valued NCHW tensors (the reference's rounded hyper latents and rounded
+    # dual-prior residuals of this picture) that REPLACE this implementation's own roundings in the encoder networks
+    # (forced-symbol replay of the gradient fixtures, tests/test_gpu_backward.py).  None in every product path.
+    _forced = None
 
     def __init__(self, spec, seed=0, precision=None):
         super().__init__()
@@ -366,8 +374,12 @@ class CodecBase(nn.Module):
             for k in (0, 1):
                 sym[k] = e.ibuf(f"{self._tag}/{tag}.sym{k}", n // 2)
                 idx[k] = e.ibuf(f"{self._tag}/{tag}.idx{k}", n // 2)
+        forced = None
+        if self._forced is not None:  # tests only (teacher forcing, see _forced)
+            forced = self._forced[tag].to(device=self.device, dtype=torch.float32).permute(0, 2, 3, 1).contiguous()
+            assert tuple(forced.shape) == (N, H, W, Cc), (tag, forced.shape)
         common = dict(y=y, fusion=fusion, params=params, y_hat=y_hat, y_q=r.get("y_q"), scales_hat=r.get("scales_hat"),
-                      y_res=r.get("y_res"), distribution=self._distribution, qkey=qkey)
+                      y_res=r.get("y_res"), distribution=self._distribution, qkey=qkey, forced_q=forced)
         e.dual_prior("enc", 0, sym=sym[0], idx=idx[0], **common)
         spatial = net.three_convs(prior_name, params)
         e.dual_prior("enc", 1, spatial=spatial, sym=sym[1], idx=idx[1], out=out, q_basic=q_basic, q_scale=q_scale,
@@ -549,6 +561,8 @@ class DMC(CodecBase):
         sym_mv_z = e.ibuf("dmc/sym_mv_z", N * 64 * mv_z.HW) if mode == "compress" else None
         self._wait_coder()  # the previous picture's device coder (if any) has read its symbol planes
         e.round_symbols(mv_z, mv_z_hat, sym_mv_z)
+        if self._forced is not None:
+            e.symbols_to_nhwc(self._forced["mv_z"].to(self.device, torch.int32).contiguous().view(-1), mv_z_hat)
         mv_y_hat, r_mv = self._mv_side(net, dv, mv_y, mv_z_hat, N, q_mv, k, mode)
         mv_hat = net.decoder_stack("mv_decoder", mv_y_hat)
         enc_cat2 = net.buf("enc_cat2", N=N, H=H // 2, W=W // 2, C=128)
@@ -566,6 +580,8 @@ class DMC(CodecBase):
         z_hat = net.buf("z_hat", like=z, C=64)
         sym_z = e.ibuf("dmc/sym_z", N * 64 * z.HW) if mode == "compress" else None
         e.round_symbols(z, z_hat, sym_z)
+        if self._forced is not None:
+            e.symbols_to_nhwc(self._forced["z"].to(self.device, torch.int32).contiguous().view(-1), z_hat)
         fusion = self._y_prior(net, dv, c3, z_hat)
         y_hat = net.buf(f"dpb{k}.ref_y", like=y, C=96)
         r_y = self._dual_prior_encode("y", y, fusion, "y_spatial_prior", y_hat, self.P("y_q_basic").reshape(-1), q_y,
@@ -747,8 +763,11 @@ class DMC(CodecBase):
         return g
 
     @torch.no_grad()
-    def compress(self, x, dpb, mv_y_q_scale, y_q_scale, defer=False, coder="host", graph=False):
+    def compress(self, x, dpb, mv_y_q_scale, y_q_scale, defer=False, coder="host", graph=False, check_range=True):
         """defer=True returns {"dpb", "pending"}: call pending.finish() later for the bytes.
+        check_range: a call that returns bytes (defer=False) raises lib.KernelError if a split-fp16 kernel met an
+        activation beyond +-8188 (one status read after the picture is done); pipelined callers (defer=True, or
+        check_range=False) read Engine.check_status() / status_snapshot() themselves, as GopEncoder does per GOP.
         coder="device": opt-in lane-interleaved GPU coder (include/dcvc_hip_rans.h, its own format).
         graph=True: replay the picture's launches as a captured hipGraph (host coder, batch 1, float
         q-scales): pays when the picture is small enough for the host enqueue to be the bottleneck."""
@@ -762,6 +781,8 @@ class DMC(CodecBase):
             if defer:
                 return {"dbp": d, "dpb": d, "pending": g["pending"], "_views": g["views"]}
             streams = g["pending"].finish_all()
+            if check_range:
+                self.engine().check_status()
             return {"dbp": d, "dpb": d, "bit_stream": streams[0], "bit_streams": streams, "_views": g["views"]}
         o = self._run(x, dpb, mv_y_q_scale, y_q_scale, "compress")
         N = o["N"]  # N > 1: a batch of rate points, one independent stream per element ("bit_streams")
@@ -780,10 +801,13 @@ class DMC(CodecBase):
         if defer:
             return {"dbp": d, "dpb": d, "pending": pending, "_views": o}
         streams = pending.finish_all()
+        if check_range:
+            self.engine().check_status()
         return {"dbp": d, "dpb": d, "bit_stream": streams[0], "bit_streams": streams, "_views": o}
 
     @torch.no_grad()
-    def decompress(self, dpb, string, height, width, mv_y_q_scale, y_q_scale, coder=None, defer_check=False):
+    def decompress(self, dpb, string, height, width, mv_y_q_scale, y_q_scale, coder=None, defer_check=False,
+                   check_range=True):
         """coder: "host" (reference format), "device" (payloads of compress(coder="device")) or None =
         tell them apart by the device format's magic.  defer_check (device format only): do not
         synchronise to read the kernels' status word; the caller calls device_coder().check() later."""
@@ -794,9 +818,12 @@ class DMC(CodecBase):
             coder = "device" if string[:4] == E.DRANS_MAGIC else "host"
         self._dc_active = coder == "device"
         try:
-            return self._decompress(dpb, string, height, width, mv_y_q_scale, y_q_scale)
+            r = self._decompress(dpb, string, height, width, mv_y_q_scale, y_q_scale)
         finally:
             self._dc_active = False
+        if check_range:  # (see compress)
+            self.engine().check_status()
+        return r
 
     def _decompress(self, dpb, string, height, width, mv_y_q_scale, y_q_scale):
         e = self.engine()
@@ -830,7 +857,7 @@ class DMC(CodecBase):
         dec_feature = net.contextual_decoder(y_hat, c2, c3)
         feature = net.buf(f"dpb{k}.ref_feature", N=N, H=H, W=W, C=64)
         recon = net.buf(f"dpb{k}.ref_frame", N=N, H=H, W=W, C=3)
-        net.recon_generation(dec_feature, c1, feature, recon, clamp=True)  # recon.clamp(0, 1), :413
+        net.recon_generation(dec_feature, c1, feature, recon, clamp=self._clamp_decoded)  # recon.clamp(0, 1), :413
         if self._dc_active:
             self._dcoder.release()
             if not self._defer_check:

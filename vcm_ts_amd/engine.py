@@ -96,16 +96,22 @@ class Engine:
         self.calls = 0
         self.profile = None  # set to {} to time every conv launch with HIP events (bench.py)
         self.profile_detail = None
+        self.profile_hbm = None  # set to {} to time the HBM-bound kernels (warp, resamplers, dual prior, layout) too
         self.tape = None     # grad.Tape while a training-mode forward is being recorded
         self._edges = {}     # distribution -> device (256,) fp32 bin edges of build_indexes
         self._status = None  # device status word of the split-fp16 kernels (saturation flag)
-        self.use_small = os.environ.get("DCVC_SMALL", "1") != "0"   # dcvc_conv2d_small for <= 16 output channels
-        # dcvc_conv2d_k32 (16x16x32 MFMA, 32-channel chunks) for the stride-1 3x3 / 1x1 layers it covers; DCVC_K32=0
-        # keeps them on dcvc_conv2d (developer A/B switch: an encoder and its decoder must use the same setting)
-        self.use_k32 = os.environ.get("DCVC_K32", "1") != "0"
-        self.use_pairs = os.environ.get("DCVC_PAIR_TAPS", "1") != "0"  # tap-paired 7x7 kernel for layers with <= 8 input channels
+        # Which kernel serves a layer (conv_mfma / conv_k32 / conv_small / the tap-paired 7x7) is part of the arithmetic
+        # -- each sums in its own order -- so an encoder and its decoder must route alike.  The product routes by layer
+        # geometry alone; these switches exist for developer A/B runs (tools/) and for tests, and are read from the
+        # environment only when DCVC_DEV=1 says the process is one of those (a stray variable must not be
+        # able to make two product processes disagree).
+        dev = os.environ.get("DCVC_DEV") == "1"
+        sw = lambda name, default: os.environ.get(name, default) if dev else default
+        self.use_small = sw("DCVC_SMALL", "1") != "0"   # dcvc_conv2d_small for <= 16 output channels
+        self.use_k32 = sw("DCVC_K32", "1") != "0"       # dcvc_conv2d_k32 (16x16x32 MFMA, 32-channel chunks)
+        self.use_pairs = sw("DCVC_PAIR_TAPS", "1") != "0"  # tap-paired 7x7 kernel for layers with <= 8 input channels
         self.k32_everywhere = False  # tests: route every layer the kernel covers to it, whatever its size
-        self.k32_sizes = tuple(int(k) for k in os.environ.get("DCVC_K32_SIZES", "3").split(","))  # kernel sizes it takes (1x1 layers are HBM-bound: conv_mfma's full-line stores are 10-15 % faster there)
+        self.k32_sizes = tuple(int(k) for k in sw("DCVC_K32_SIZES", "3").split(","))  # kernel sizes it takes (1x1 layers are HBM-bound: conv_mfma's full-line stores are 10-15 % faster there)
         # fp16x3 mode clamps |activation| > 8188 on load; every convolution launch of that mode flags outputs beyond
         # that magnitude in the status word (read_status() / check_status()).  The check is a running maximum (two
         # v_max3_f32 per four outputs, one atomic per workgroup only when it fires) and is ON by default since round 3;
@@ -156,6 +162,26 @@ class Engine:
         v = self.read_status()
         if v:
             raise lib.KernelError(f"split-fp16 activation range exceeded (status {v}): |x| > 8188; use precision='fp32'")
+
+    def status_snapshot(self):
+        """Asynchronous form of check_status() for pipelined callers (GopEncoder): copies the status word to pinned host
+        memory behind everything enqueued so far on the current stream and returns a callable that waits for THAT copy
+        only (not for later work) and raises like check_status().  None when no split-fp16 kernel has run."""
+        if self._status is None:
+            return None
+        host = torch.empty(1, dtype=torch.int32, pin_memory=True)
+        host.copy_(self._status, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device))
+
+        def check():
+            ev.synchronize()
+            v = int(host[0])
+            if v:
+                self._status.zero_()
+                raise lib.KernelError(f"split-fp16 activation range exceeded (status {v}): |x| > 8188; use precision='fp32'")
+
+        return check
 
     def ibuf(self, name, n) -> torch.Tensor:
         key = (name, n, "i32")
@@ -217,8 +243,9 @@ class Engine:
                       "copy_channels")
         else:
             x = x.contiguous()
-            lib.check(self.L.dcvc_nchw_to_nhwc(x.data_ptr(), out.ptr, out.cs, N, C_, H, W, self.stream()),
-                      "nchw_to_nhwc")
+            self._hbm("nchw_to_nhwc", f"C{C_} {H}x{W}", N * C_ * H * W * 8,
+                      lambda: lib.check(self.L.dcvc_nchw_to_nhwc(x.data_ptr(), out.ptr, out.cs, N, C_, H, W, self.stream()),
+                                        "nchw_to_nhwc"))
         self.calls += 1
         return out
 
@@ -428,7 +455,7 @@ class Engine:
         pk.k32 = q
         return q
 
-    def k32_capable(self, pk: PackedConv, stride, out: View, res, res2, gate) -> bool:
+    def k32_capable(self, pk: PackedConv, stride, out: View, res, res2, gate, srcs=()) -> bool:
         """Layers routed to dcvc_conv2d_k32: fp16x3, 3x3, stride 1, every input segment a multiple of 32 channels,
         16-byte-addressable epilogue (4-channel groups of out / residuals) -- what the kernel covers -- and, from the
         per-layer comparison inside a 1080p P picture (profiles/r03_k32_vs_conv_mfma_in_pipeline.txt), only where it
@@ -440,7 +467,12 @@ class Engine:
         cfin = pk.Cout // 4 if pk.ps else pk.Cout
         al = lambda v: v is None or (v.ptr % 16 == 0 and v.cs % 4 == 0)
         covered = (pk.ks in self.k32_sizes and stride == 1 and all(c % 32 == 0 for c in pk.seg_C) and cfin % 4 == 0
-                   and al(out) and al(res) and al(res2) and (gate is None or gate.data_ptr() % 16 == 0))
+                   and al(out) and al(res) and al(res2) and (gate is None or gate.data_ptr() % 16 == 0)
+                   # what dcvc_conv2d_k32 itself refuses: misaligned source views, and pictures whose
+                   # pixel index or channel stride does not fit its 24-bit address multiplies -- those layers stay
+                   # on dcvc_conv2d instead of failing with DCVC_E_ARG
+                   and all(al(s) for s in srcs) and out.H * out.W < (1 << 24)
+                   and all(v is None or v.cs * 4 < (1 << 24) for v in (out, res, res2, *srcs)))
         if not covered or self.k32_everywhere:
             return covered
         # per-IMAGE geometry, never the batch size: a batch of rate points is decoded one element at a time
@@ -500,7 +532,7 @@ class Engine:
         a.nseg, a.N, a.Hin, a.Win = len(srcs), s0.N, s0.H, s0.W
         a.in_act, a.in_slope = (0, 0.0) if in_slope is None else (1, in_slope)
         small = band is None and self.small_capable(pk, stride, gate, res2, chan_partial)
-        k32 = not small and self.k32_capable(pk, stride, out, res, res2, gate)
+        k32 = not small and self.k32_capable(pk, stride, out, res, res2, gate, srcs)
         paired = not small and not k32 and self.pair_capable(pk, stride)
         wq = self.pack_small(pk) if small else (self.pack_k32(pk) if k32 else (self.pack_paired(pk) if paired else pk))
         a.pair_taps = int(paired)
@@ -546,6 +578,28 @@ class Engine:
         self._rec("conv", pk, tuple(srcs), out, stride, in_slope, out_slope, res, gate, res2)
         return out
 
+    def _hbm(self, kernel, shape, abytes, launch):
+        """Launch one of the HBM-bound kernels; while profiling (bench.py sets profile_hbm = {}) bracket it with HIP
+        events on the launch stream and record its ALGORITHMIC bytes (every operand once: SURVEY 8d)."""
+        if self.profile_hbm is None:
+            return launch()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+        launch()
+        ev1.record()
+        self.profile_hbm.setdefault((kernel, shape), []).append((ev0, ev1, float(abytes)))
+
+    def collect_profile_hbm(self):
+        """[{kernel, shape, launches, avg_us, algorithmic_bytes, tb_per_s}] of the launches recorded by _hbm()."""
+        torch.cuda.synchronize(self.device)
+        out = []
+        for (kernel, shape), v in (self.profile_hbm or {}).items():
+            ms = sum(r[0].elapsed_time(r[1]) for r in v)
+            by = sum(r[2] for r in v)
+            out.append({"kernel": kernel, "shape": shape, "launches": len(v), "avg_us": round(ms / len(v) * 1e3, 2),
+                        "algorithmic_bytes": int(by / len(v)), "tb_per_s": round(by / (ms * 1e-3) / 1e12, 3) if ms > 0 else None})
+        return out
+
     def collect_profile(self):
         torch.cuda.synchronize(self.device)
         return {k: {"flops": sum(r[2] for r in v), "bytes": sum(r[3] for r in v),
@@ -554,22 +608,27 @@ class Engine:
 
     # ------------------------------------------------------------------ resampling
     def warp(self, src: View, flow: View, out: View):
-        lib.check(self.L.dcvc_warp(src.ptr, src.cs, flow.ptr, flow.cs, out.ptr, out.cs, src.N, src.H, src.W, src.C,
-                                   self.stream()), "warp")
+        # (C * 4 * 2 + 8) bytes per pixel: source and result once, the flow once
+        self._hbm("warp", f"C{src.C} {src.H}x{src.W}", src.N * src.H * src.W * (8 * src.C + 8),
+                  lambda: lib.check(self.L.dcvc_warp(src.ptr, src.cs, flow.ptr, flow.cs, out.ptr, out.cs, src.N, src.H, src.W,
+                                                     src.C, self.stream()), "warp"))
         self.calls += 1
         self._rec("warp", src, flow, out)
         return out
 
     def up2(self, src: View, out: View, scale=1.0, out2: View = None):
-        lib.check(self.L.dcvc_up2(src.ptr, src.cs, out.ptr, out.cs, out2.ptr if out2 else None,
-                                  out2.cs if out2 else 0, src.N, src.H, src.W, src.C, scale, self.stream()), "up2")
+        n_in = src.N * src.H * src.W * src.C * 4
+        self._hbm("up2", f"C{src.C} {src.H}x{src.W}", n_in * (1 + 4 * (2 if out2 else 1)),
+                  lambda: lib.check(self.L.dcvc_up2(src.ptr, src.cs, out.ptr, out.cs, out2.ptr if out2 else None,
+                                                    out2.cs if out2 else 0, src.N, src.H, src.W, src.C, scale, self.stream()), "up2"))
         self.calls += 1
         self._rec("up2", src, out, scale, out2)
         return out
 
     def down2(self, src: View, out: View, scale=1.0, avgpool_order=False):
-        lib.check(self.L.dcvc_down2(src.ptr, src.cs, out.ptr, out.cs, src.N, src.H, src.W, src.C, scale,
-                                    int(avgpool_order), self.stream()), "down2")
+        self._hbm("down2", f"C{src.C} {src.H}x{src.W}", src.N * src.H * src.W * src.C * 5,
+                  lambda: lib.check(self.L.dcvc_down2(src.ptr, src.cs, out.ptr, out.cs, src.N, src.H, src.W, src.C, scale,
+                                                      int(avgpool_order), self.stream()), "down2"))
         self.calls += 1
         self._rec_unary("down2", src, out, scale)
         return out
@@ -582,8 +641,9 @@ class Engine:
         return out
 
     def copy(self, src: View, out: View):
-        lib.check(self.L.dcvc_copy_channels(src.ptr, src.cs, out.ptr, out.cs, src.N * src.H * src.W, src.C,
-                                            self.stream()), "copy_channels")
+        self._hbm("copy_channels", f"C{src.C} {src.H}x{src.W}", src.N * src.H * src.W * src.C * 8,
+                  lambda: lib.check(self.L.dcvc_copy_channels(src.ptr, src.cs, out.ptr, out.cs, src.N * src.H * src.W, src.C,
+                                                              self.stream()), "copy_channels"))
         self.calls += 1
         self._rec_unary("copy", src, out)
         return out
@@ -633,7 +693,7 @@ class Engine:
 
     def dual_prior(self, mode, step, *, y: View = None, fusion: View, spatial: View = None, params: View,
                    y_hat: torch.Tensor, y_q=None, y_res=None, scales_hat=None, sym=None, idx=None, out: View = None,
-                   q_basic=None, q_scale=None, distribution="laplace", qkey=None):
+                   q_basic=None, q_scale=None, distribution="laplace", qkey=None, forced_q=None):
         a = lib.DualPriorArgs()
         Cc = fusion.C // 3
         if y is not None:
@@ -644,7 +704,7 @@ class Engine:
         a.params, a.params_cs = params.ptr, params.cs
         a.y_hat = y_hat.data_ptr()
         for nm, t in (("y_q", y_q), ("y_res", y_res), ("scales_hat", scales_hat), ("sym", sym), ("idx", idx),
-                      ("q_basic", q_basic), ("q_scale", q_scale)):
+                      ("q_basic", q_basic), ("q_scale", q_scale), ("forced_q", forced_q)):
             if t is not None:
                 setattr(a, nm, t.data_ptr())
         if out is not None:
@@ -653,7 +713,12 @@ class Engine:
         a.idx_edges = self.index_edges(distribution).data_ptr()
         fn = {"enc": self.L.dcvc_dual_prior_enc, "dec_index": self.L.dcvc_dual_prior_dec_index,
               "dec_apply": self.L.dcvc_dual_prior_dec_apply}[mode]
-        lib.check(fn(C.byref(a), self.stream()), "dual_prior_" + mode)
+        # operands once each, per element of the (N,H,W,C) planes: step 0 reads y + fusion (3) and writes params (4) +
+        # y_hat / symbol / index halves; step 1 reads y + fusion (3) + spatial (2) + y_hat and writes out + the halves
+        per_el = {("enc", 0): 4 + 4 + 2.0, ("enc", 1): 7 + 1 + 2.0, ("dec_index", 0): 3 + 3 + 0.5, ("dec_index", 1): 3 + 0.5,
+                  ("dec_apply", 0): 3 + 0.5 + 1.5, ("dec_apply", 1): 5 + 0.5 + 1.5}[(mode, step)]
+        self._hbm(f"dual_prior_{mode}{step}", f"C{Cc} {fusion.H}x{fusion.W}", fusion.N * fusion.H * fusion.W * Cc * 4 * per_el,
+                  lambda: lib.check(fn(C.byref(a), self.stream()), "dual_prior_" + mode))
         self.calls += 1
         if mode == "enc":
             self._rec("dual_prior", step, y, fusion, spatial, params, y_hat, y_res, scales_hat, out, q_basic, q_scale,

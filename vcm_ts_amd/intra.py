@@ -80,7 +80,7 @@ class IntraNoAR(CodecBase):
                 "bpp": bpp_y + bpp_z, "bpp_y": bpp_y, "bpp_z": bpp_z, "_views": o}
 
     @torch.no_grad()
-    def compress(self, x, q_scale, defer=False, coder="host"):
+    def compress(self, x, q_scale, defer=False, coder="host", check_range=True):
         if self.entropy_coder is None:
             raise RuntimeError("call update() before compress()/decompress()")
         o = self._run(x, q_scale, "compress")
@@ -95,10 +95,12 @@ class IntraNoAR(CodecBase):
         if defer:
             return {"pending": pending, "x_hat": o["x_hat"].nchw(), "_views": o}
         streams = pending.finish_all()
+        if check_range:  # split-fp16 range guard (DMC.compress says when a caller reads it itself)
+            self.engine().check_status()
         return {"bit_stream": streams[0], "bit_streams": streams, "x_hat": o["x_hat"].nchw(), "_views": o}
 
     @torch.no_grad()
-    def decompress(self, bit_stream, height, width, q_scale, coder=None, defer_check=False):
+    def decompress(self, bit_stream, height, width, q_scale, coder=None, defer_check=False, check_range=True):
         self._defer_check = defer_check
         if self.entropy_coder is None:
             raise RuntimeError("call update() before compress()/decompress()")
@@ -106,9 +108,12 @@ class IntraNoAR(CodecBase):
             coder = "device" if bit_stream[:4] == E.DRANS_MAGIC else "host"
         self._dc_active = coder == "device"
         try:
-            return self._decompress(bit_stream, height, width, q_scale)
+            r = self._decompress(bit_stream, height, width, q_scale)
         finally:
             self._dc_active = False
+        if check_range:
+            self.engine().check_status()
+        return r
 
     def _decompress(self, bit_stream, height, width, q_scale):
         e = self.engine()
@@ -124,7 +129,7 @@ class IntraNoAR(CodecBase):
         fusion = net.three_convs("y_prior_fusion", net.hyper_dec("hyper_dec", z_hat))
         y_hat = net.buf("y_hat", N=1, H=zh * 4, W=zw * 4, C=self.N)
         self._dual_prior_decode("y", fusion, "y_spatial_prior", y_hat, self.P("q_basic").reshape(-1), q)
-        x_hat = self._synthesis(net, y_hat, 1, zh * 64, zw * 64, clamp=True)  # .clamp_(0, 1), :199
+        x_hat = self._synthesis(net, y_hat, 1, zh * 64, zw * 64, clamp=self._clamp_decoded)  # .clamp_(0, 1), :199
         if self._dc_active:
             self._dcoder.release()
             if not self._defer_check:

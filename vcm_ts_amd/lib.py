@@ -81,7 +81,7 @@ class DualPriorArgs(C.Structure):
         ("y_hat", C.c_void_p), ("y_q", C.c_void_p), ("y_res", C.c_void_p), ("scales_hat", C.c_void_p),
         ("sym", C.c_void_p), ("idx", C.c_void_p), ("out", C.c_void_p), ("out_cs", C.c_int32),
         ("q_basic", C.c_void_p), ("q_scale", C.c_void_p), ("N", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
-        ("C", C.c_int32), ("step", C.c_int32), ("idx_edges", C.c_void_p),
+        ("C", C.c_int32), ("step", C.c_int32), ("idx_edges", C.c_void_p), ("forced_q", C.c_void_p),
     ]
 
 
@@ -140,6 +140,7 @@ _SIGS = {
     "dcvc_conv_small_pack_weights": [vp, vp, i32, i32, i32, vp, vp, vp],
     "dcvc_conv2d_k32": [C.POINTER(ConvArgs), vp],
     "dcvc_conv_k32_pack_weights": [vp, vp, i32, i32, i32, vp, i32, vp, vp],
+    "dcvc_conv_k32_set_waves": [i32],
     "dcvc_warp": [vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, vp],
     "dcvc_up2": [vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, f32, vp],
     "dcvc_down2": [vp, i32, vp, i32, i32, i32, i32, i32, f32, i32, vp],

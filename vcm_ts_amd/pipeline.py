@@ -89,8 +89,10 @@ class GopEncoder:
 
         def retire(item):  # host half of a picture: wait for its planes, rANS-code them
             nonlocal bits
-            kind, q, pending, t = item
+            kind, q, pending, t, guards = item
             payload = pending.finish()
+            for check in guards:  # range guard of the split-fp16 kernels: a GOP whose activations were
+                check()           # clamped must not be written out as if it were fine -- raises lib.KernelError
             out.append((kind, q, payload))
             bits += (len(payload) + (14 if kind == "I" else 8)) * 8  # >IIHI / >HHI headers
             if sink is not None:
@@ -101,13 +103,20 @@ class GopEncoder:
         # so the GPU works on t while the CPU codes t-1.  The DPB never leaves the device.
         for t, x in enumerate(frames):
             if t % self.gop == 0:
-                r = self.i_net.compress(x, q_i, defer=True, coder=self.coder)
+                r = self.i_net.compress(x, q_i, defer=True, coder=self.coder, check_range=False)
                 dpb = {"ref_frame": r["x_hat"], "ref_feature": None, "ref_y": None, "ref_mv_y": None}
                 item = ("I", (qi_idx,), r["pending"], t)
             else:
-                r = self.p_net.compress(x, dpb, q_mv_y, q_y, defer=True, coder=self.coder, graph=self.graphs)
+                r = self.p_net.compress(x, dpb, q_mv_y, q_y, defer=True, coder=self.coder, graph=self.graphs, check_range=False)
                 dpb = r["dpb"]
                 item = ("P", (qmv_idx, qy_idx), r["pending"], t)
+            # once per GOP (behind its last picture; a trailing partial GOP is covered after the loop): the status
+            # word of both engines, read asynchronously -- the copy rides behind the picture's kernels and is looked
+            # at when that picture is retired, so the host never drains the GPU for it
+            guards = ()
+            if t % self.gop == self.gop - 1:
+                guards = tuple(c for c in (self.i_net.engine().status_snapshot(), self.p_net.engine().status_snapshot()) if c)
+            item = item + (guards,)
             if on_recon is not None:  # reconstruction == what the decoder will produce (clamped)
                 on_recon(t, dpb["ref_frame"])
             if prev is not None:
@@ -116,6 +125,8 @@ class GopEncoder:
             yield t
         if prev is not None:
             retire(prev)
+            self.i_net.engine().check_status()  # (everything is retired: these reads find the GPU idle)
+            self.p_net.engine().check_status()
         res.update(coded=out, bits=bits, dpb=dpb)
 
     def decode_gop(self, coded, height, width):
@@ -130,13 +141,16 @@ class GopEncoder:
             if dev_fmt:
                 deferred.add(net)
             if kind == "I":
-                x_hat = net.decompress(payload, height, width, q[0] / 100, defer_check=dev_fmt)["x_hat"]
+                x_hat = net.decompress(payload, height, width, q[0] / 100, defer_check=dev_fmt, check_range=False)["x_hat"]
                 dpb = {"ref_frame": x_hat, "ref_feature": None, "ref_y": None, "ref_mv_y": None}
             else:
-                dpb = net.decompress(dpb, payload, height, width, q[0] / 100, q[1] / 100, defer_check=dev_fmt)["dpb"]
+                dpb = net.decompress(dpb, payload, height, width, q[0] / 100, q[1] / 100, defer_check=dev_fmt,
+                                     check_range=False)["dpb"]
             recs.append(dpb["ref_frame"].clone())
         for net in deferred:
             net.device_coder().check()
+        self.i_net.engine().check_status()  # range guard of the split-fp16 kernels, once per call
+        self.p_net.engine().check_status()
         return recs
 
 
@@ -157,16 +171,18 @@ class ConcurrentGopEncoder:
         self.device = dev
         self.streams = [torch.cuda.Stream(dev) for _ in self.encoders]
 
-    def encode_gops(self, sequences, q_i, q_mv_y, q_y):
-        """sequences: up to `streams` iterables of padded pictures (one GOP sequence each).  Returns a
-        list of (coded, bits, dpb) in the same order."""
+    def encode_gops(self, sequences, q_i, q_mv_y, q_y, sinks=None, on_recons=None):
+        """sequences: up to `streams` iterables of padded pictures (one sequence of whole GOPs each; an iterable is
+        pulled INSIDE its stream, so a generator may upload its pictures there).  Returns a list of
+        (coded, bits, dpb) in the same order.  sinks / on_recons: per-sequence callbacks of GopEncoder.encode_gop."""
         assert len(sequences) <= len(self.encoders)
         cur = torch.cuda.current_stream(self.device)
         results = [{} for _ in sequences]
         gens = []
         for k, seq in enumerate(sequences):
             self.streams[k].wait_stream(cur)  # the pictures were produced on the caller's stream
-            gens.append(self.encoders[k].encode_steps(seq, q_i, q_mv_y, q_y, results[k]))
+            gens.append(self.encoders[k].encode_steps(seq, q_i, q_mv_y, q_y, results[k], sink=sinks[k] if sinks else None,
+                                                      on_recon=on_recons[k] if on_recons else None))
         live = list(range(len(gens)))
         while live:
             for k in list(live):

@@ -19,7 +19,7 @@ import torch
 from PIL import Image
 
 from . import stream as S
-from .pipeline import GopEncoder, pad_frame
+from .pipeline import pad_frame
 
 
 class PNGReader:
@@ -97,14 +97,51 @@ def _save_array(a, path):
     Image.fromarray(np.clip(np.rint(a * 255), 0, 255).astype(np.uint8)).save(path)
 
 
-def save_torch_image(img: torch.Tensor, path, pool=None):
-    """stream_helper.py:148-153.  pool: a ThreadPoolExecutor that takes the PNG encoding (the device -> host copy still
+class PNGWriters:
+    """A bounded pool of PNG-encoding threads: at most 2 x workers pictures (25 MB of float32 each at 1080p) wait in
+    host memory, and a failed write (disk full, bad path) surfaces in the caller -- at the next save or at close() --
+    instead of being dropped with its future.  workers == 0: write inline, as the reference does."""
+
+    def __init__(self, workers):
+        from collections import deque
+        from concurrent.futures import ThreadPoolExecutor
+
+        self.pool = ThreadPoolExecutor(max_workers=workers) if workers > 0 else None
+        self.pending, self.limit = deque(), 2 * max(workers, 1)
+
+    def submit(self, a, path):
+        if self.pool is None:
+            return _save_array(a, path)
+        while len(self.pending) >= self.limit:
+            self.pending.popleft().result()  # re-raises a writer's exception
+        self.pending.append(self.pool.submit(_save_array, a, path))
+
+    def close(self):
+        try:
+            while self.pending:
+                self.pending.popleft().result()
+        finally:
+            if self.pool is not None:
+                self.pool.shutdown(wait=True)
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, et, ev, tb):
+        if et is None:
+            self.close()
+        elif self.pool is not None:  # already failing: do not mask the first error with a writer's
+            self.pool.shutdown(wait=True, cancel_futures=True)
+
+
+def save_torch_image(img: torch.Tensor, path, writers: PNGWriters = None):
+    """stream_helper.py:148-153.  writers: a PNGWriters pool that takes the PNG encoding (the device -> host copy still
     happens here, while the tensor is valid)."""
     a = img.squeeze(0).permute(1, 2, 0).detach().cpu().numpy()
-    if pool is None:
+    if writers is None:
         _save_array(a, path)
     else:
-        pool.submit(_save_array, a, path)
+        writers.submit(a, path)
 
 
 def _nets(device, precision, i_ckpt=None, p_ckpt=None):
@@ -140,99 +177,150 @@ def rate_point_q_scales(i_q_scales, y_q_scales, mv_y_q_scales, rate_count, quali
 
 
 def encode_folder(frames_dir, bin_dir, recon_dir=None, gop=32, q=(1.0, 1.0, 1.0), device="cuda:0", precision=None,
-                  i_ckpt=None, p_ckpt=None, max_frames=None, coder="host", io_workers=8, nets=None):
+                  i_ckpt=None, p_ckpt=None, max_frames=None, coder="host", io_workers=8, nets=None, gop_streams=1):
     """Returns (bits per frame list, (height, width)).  coder="device": payloads in the opt-in GPU
     format (include/dcvc_hip_rans.h) inside the same .bin containers; decode_folder reads both.
     io_workers: host threads decoding PNGs ahead of the encoder (0: read in the encode loop as run_dcvc does).
-    nets: (i_frame_net, p_frame_net) already on the device, instead of building them here."""
+    nets: (i_frame_net, p_frame_net) already on the device -- or a list of such pairs, one per GOP stream -- instead
+    of building them here.
+    gop_streams (round 4): GOPs of the folder in flight together on the GPU (pipeline.ConcurrentGopEncoder: own codec
+    instances, DPB and HIP stream each; stream k codes GOPs k, k + K, k + 2K, ...), fed by ONE pool of PNG-decoding
+    threads.  GOPs are independent (every GOP starts from an I picture, video_coder.py:122-130), so the .bin files are
+    byte-identical to the one-stream loop's (tests/test_gpu_codec.py); each stream holds its own workspace (~33 GB at
+    1088x1920)."""
+    from collections import deque
+    from concurrent.futures import ThreadPoolExecutor
+
+    from .pipeline import ConcurrentGopEncoder
+
     os.makedirs(bin_dir, exist_ok=True)
     if recon_dir:
         os.makedirs(recon_dir, exist_ok=True)
     dev = torch.device(device)
-    enc = GopEncoder(*(nets if nets is not None else _nets(dev, precision, i_ckpt, p_ckpt)), gop_size=gop, coder=coder)
     reader = PNGReader(frames_dir)
-    size, bits = [None], []
+    n_frames = 0
+    while os.path.exists(reader.path_of(n_frames + 1)) and (max_frames is None or n_frames < max_frames):
+        n_frames += 1
+    n_gops = (n_frames + gop - 1) // gop
+    K = max(1, min(int(gop_streams), n_gops))
+    pairs = [nets] if (nets is not None and not isinstance(nets, list)) else list(nets or [])
+    made = iter(pairs[:K] + [None] * K)
+    cenc = ConcurrentGopEncoder(lambda: next(made) or _nets(dev, precision, i_ckpt, p_ckpt), gop_size=gop, streams=K, coder=coder)
+    size, bits = [None], {}
+    pool = ThreadPoolExecutor(max_workers=io_workers) if io_workers > 0 else None
 
-    def frames():
+    def global_index(k, t):  # picture t of stream k's sequence -> 0-based frame number in the folder
+        return ((t // gop) * K + k) * gop + t % gop
+
+    def raw_frames(k):
+        """Stream k's pictures in its coding order as (H, W, 3) uint8 arrays, decoded up to `depth` ahead by the shared pool."""
+        order = [global_index(k, t) for t in range(((n_gops - k + K - 1) // K) * gop)]
+        order = [g for g in order if g < n_frames]
+        if pool is None:
+            for g in order:
+                yield reader.load_u8(reader.path_of(g + 1))
+            return
+        depth, pending, nxt = max(2, 2 * io_workers // K), deque(), 0
+        while nxt < len(order) or pending:
+            while nxt < len(order) and len(pending) < depth:
+                pending.append(pool.submit(reader.load_u8, reader.path_of(order[nxt] + 1)))
+                nxt += 1
+            yield pending.popleft().result()
+
+    def frames(k):
         # uint8 pixels go to the device through a ring of pinned buffers on a copy stream of their own: a pageable
         # `.to(device)` would be a synchronous copy queued BEHIND the previous picture's kernels, i.e. the host could
         # never run ahead of the GPU (measured: 26 ms of every picture's 66 spent blocked in that call)
         n, ring, done, copy_stream = 0, [], [], torch.cuda.Stream(dev) if dev.type == "cuda" else None
-        for rgb in reader.prefetching(workers=io_workers, depth=2 * io_workers, raw=True) if io_workers > 0 else reader.sequential():
-            if max_frames is not None and n >= max_frames:
-                return
-            if rgb.dtype == np.uint8 and copy_stream is not None:
+        for rgb in raw_frames(k):
+            if copy_stream is not None:
                 if not ring:
                     ring = [torch.empty(rgb.shape, dtype=torch.uint8).pin_memory() for _ in range(3)]
                     done = [None] * len(ring)
                 assert tuple(rgb.shape) == tuple(ring[0].shape), "all frames must have one size"
-                k = n % len(ring)
-                if done[k] is not None:
-                    done[k].synchronize()  # the copy that last read this pinned buffer (three pictures ago)
-                ring[k].numpy()[...] = rgb
+                j = n % len(ring)
+                if done[j] is not None:
+                    done[j].synchronize()  # the copy that last read this pinned buffer (three pictures ago)
+                ring[j].numpy()[...] = rgb
                 with torch.cuda.stream(copy_stream):
-                    d = ring[k].to(dev, non_blocking=True)
-                    done[k] = torch.cuda.Event()
-                    done[k].record(copy_stream)
-                cur = torch.cuda.current_stream(dev)
-                cur.wait_event(done[k])
+                    d = ring[j].to(dev, non_blocking=True)
+                    done[j] = torch.cuda.Event()
+                    done[j].record(copy_stream)
+                cur = torch.cuda.current_stream(dev)  # (this GOP stream's: ConcurrentGopEncoder pulls frames inside it)
+                cur.wait_event(done[j])
                 d.record_stream(cur)
                 x = u8_to_unit_float(d)
-            elif rgb.dtype == np.uint8:
-                x = u8_to_unit_float(torch.from_numpy(np.array(rgb)).to(dev))
             else:
-                x = torch.from_numpy(rgb)[None].to(dev)
+                x = u8_to_unit_float(torch.from_numpy(np.array(rgb)).to(dev))
             if size[0] is None:
                 size[0] = tuple(x.shape[-2:])
             assert tuple(x.shape[-2:]) == size[0], "all frames must have one size"
             n += 1
             yield pad_frame(x)
 
-    def sink(kind, qidx, payload, t):
-        path = os.path.join(bin_dir, f"im{str(t + 1).zfill(5)}.bin")
-        if kind == "I":
-            S.encode_i(size[0][0], size[0][1], qidx[0], payload, path)
-        else:
-            S.encode_p(payload, qidx[0], qidx[1], path)
-        bits.append(S.filesize(path) * 8)
+    def sink_of(k):
+        def sink(kind, qidx, payload, t):
+            g = global_index(k, t)
+            path = os.path.join(bin_dir, f"im{str(g + 1).zfill(5)}.bin")
+            if kind == "I":
+                S.encode_i(size[0][0], size[0][1], qidx[0], payload, path)
+            else:
+                S.encode_p(payload, qidx[0], qidx[1], path)
+            bits[g] = S.filesize(path) * 8
 
-    from concurrent.futures import ThreadPoolExecutor
+        return sink
 
-    def on_recon(t, ref_frame):
-        if recon_dir:
+    def recon_of(k):
+        def on_recon(t, ref_frame):
             h, w = size[0]
-            save_torch_image(ref_frame[..., :h, :w], os.path.join(recon_dir, f"im{str(t + 1).zfill(5)}.png"), savers)
+            save_torch_image(ref_frame[..., :h, :w], os.path.join(recon_dir, f"im{str(global_index(k, t) + 1).zfill(5)}.png"), savers)
 
-    with ThreadPoolExecutor(max_workers=max(io_workers, 1)) as savers, torch.no_grad():
-        enc.encode_gop(frames(), q[0], q[1], q[2], sink=sink, on_recon=on_recon)
-    return bits, size[0]
+        return on_recon if recon_dir else None
+
+    # (GopEncoder reads the split-fp16 range guard once per GOP and raises lib.KernelError: no .bin of a clamped GOP
+    # is reported as a success)
+    try:
+        with PNGWriters(io_workers) as savers, torch.no_grad():
+            cenc.encode_gops([frames(k) for k in range(K)], q[0], q[1], q[2], sinks=[sink_of(k) for k in range(K)],
+                             on_recons=[recon_of(k) for k in range(K)])
+    finally:
+        if pool is not None:
+            pool.shutdown(wait=True, cancel_futures=True)
+    return [bits[g] for g in sorted(bits)], size[0]
 
 
 def decode_folder(bin_dir, recon_dir, height, width, gop=32, device="cuda:0", precision=None, i_ckpt=None, p_ckpt=None,
                   io_workers=8):
-    from concurrent.futures import ThreadPoolExecutor
-
     os.makedirs(recon_dir, exist_ok=True)
     dev = torch.device(device)
     i_net, p_net = _nets(dev, precision, i_ckpt, p_ckpt)
     i_net.update()
     p_net.update()
     t, dpb = 0, None
-    with ThreadPoolExecutor(max_workers=max(io_workers, 1)) as savers, torch.no_grad():
+
+    def range_guard():  # once per GOP: raises lib.KernelError if a split-fp16 kernel clamped an activation
+        i_net.engine().check_status()
+        p_net.engine().check_status()
+
+    with PNGWriters(io_workers) as savers, torch.no_grad():
         while True:
             path = os.path.join(bin_dir, f"im{str(t + 1).zfill(5)}.bin")
             if not os.path.exists(path):
                 break
             if t % gop == 0:
+                if t:
+                    range_guard()
                 h, w, qi, payload = S.decode_i(path)
                 assert (h, w) == (height, width)
-                x_hat = i_net.decompress(payload, h, w, qi / 100)["x_hat"]
+                x_hat = i_net.decompress(payload, h, w, qi / 100, check_range=False)["x_hat"]
                 dpb = {"ref_frame": x_hat, "ref_feature": None, "ref_y": None, "ref_mv_y": None}
             else:
                 qmv, qy, payload = S.decode_p(path)
-                dpb = p_net.decompress(dpb, payload, height, width, qmv / 100, qy / 100)["dpb"]
+                dpb = p_net.decompress(dpb, payload, height, width, qmv / 100, qy / 100, check_range=False)["dpb"]
             save_torch_image(dpb["ref_frame"][..., :height, :width], os.path.join(recon_dir, f"im{str(t + 1).zfill(5)}.png"), savers)
             t += 1
+        if t:
+            range_guard()
     return t
 
 
@@ -249,6 +337,8 @@ def main():
                    help="with --quality: the reference's rate-point selection (video_coder.py RATE_COUNT / QUALITY): "
                         "q-scales interpolated in log space between the anchors stored in the checkpoints")
     e.add_argument("--quality", type=int, default=None)
+    e.add_argument("--gop-streams", type=int, default=1,
+                   help="GOPs of the folder in flight together on the GPU (same .bin bytes; ~33 GB of workspace each at 1080p)")
     e.add_argument("--coder", default="host", choices=["host", "device"],
                    help="host: the reference's bitstream (default); device: opt-in GPU entropy coder, own format")
     d = sub.add_parser("decode")
@@ -283,7 +373,7 @@ def main():
             q = rate_point_q_scales(i_qs, y_qs, mv_qs, a.rate_count, a.quality)
             print(f"rate point {a.quality} of {a.rate_count}: q_i {q[0]:.4f}  q_mv_y {q[1]:.4f}  q_y {q[2]:.4f}")
         bits, size = encode_folder(a.frames, a.bins, a.recon, a.gop, q, a.device, a.precision, a.i_ckpt, a.p_ckpt,
-                                   coder=a.coder, io_workers=a.io_workers)
+                                   coder=a.coder, io_workers=a.io_workers, gop_streams=a.gop_streams)
         print(f"{len(bits)} pictures, {size[0]}x{size[1]}, {sum(bits)} bits, {sum(bits) / (len(bits) * size[0] * size[1]):.4f} bpp")
     else:
         n = decode_folder(a.bins, a.recon, a.height, a.width, a.gop, a.device, a.precision, a.i_ckpt, a.p_ckpt, io_workers=a.io_workers)
