@@ -27,6 +27,7 @@ sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 PEAK_F16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md, "Peak BF16/FP16 MFMA" (dense)
+PEAK_HBM_TBS = 8.0             # MI355X_MICROARCH.md, HBM3E
 
 
 def synth_sequence(dev, n, h, w, seed):
@@ -258,6 +259,10 @@ def train_workload(args, dev, rank, world):
     prec = "fp32" if args.precision == "fp32" else "fp16x3"
     model = build_model(make_cfg(lambdas=(85.0, 170.0, 380.0, 840.0)), precision=prec).to(dev).train()
     model.activate_modules_all()
+    # the `single` recursion (one picture's backward before the next picture's forward): the picture's launches are
+    # replayed from captured hipGraphs (same launches, same results: tests/test_gpu_wrapper.py); --eager-training
+    # issues them from Python as rounds 1-3 did
+    model.dmc.graph_training = not getattr(args, "eager_training", False)
     net = model
     if torch.distributed.is_available() and torch.distributed.is_initialized():
         # also with ONE rank under a launcher: DistributedDataParallel's bucketed all-reduce then runs over RCCL
@@ -286,7 +291,9 @@ def train_workload(args, dev, rank, world):
     dt, loss = timed_region(lambda: run(args.warmup, args.steps), dev)
     eng = model.dmc.engine()
     eng.profile = {}
+    graphed, model.dmc.graph_training = model.dmc.graph_training, False  # (events go around Python-issued launches)
     run(0, 1)
+    model.dmc.graph_training = graphed
     prof = eng.collect_profile()
     eng.profile = None
     dom = prof.get("conv3x3s1", {"flops": 0.0, "ms": 1.0, "launches": 0})
@@ -299,7 +306,8 @@ def train_workload(args, dev, rank, world):
            "config": {"workload": "trainer.py / trainer_multi.py optimiser step (configs[2] at N=1, configs[3] at N>1): "
                                   "forward_one_frame + backward + AdamW, single mode, uniform-random clips, random-init weights",
                       "batch_per_gpu": batch, "global_batch": batch * world, "height": size, "width": size, "precision": prec,
-                      "parallelism": f"ddp x{world} ({args.dist_backend})" if net is not model else "single GPU", "final_loss": round(loss, 4)},
+                      "parallelism": f"ddp x{world} ({args.dist_backend})" if net is not model else "single GPU", "final_loss": round(loss, 4),
+                      "launch_mode": "hipGraph replay of the picture's forward and reverse pass" if model.dmc.graph_training else "eager (Python-issued launches)"},
            "roofline": {"bound": "mfma", "kernel": "conv_mfma<3,1,*> forward + data-gradient launches of one step",
                         "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
                         "traffic": None, "launches": dom["launches"]}}
@@ -359,6 +367,8 @@ def main():
                          "encode: BASELINE configs[1] (the headline metric, default); decode: the same GOPs through "
                          "decompress (payloads made once, untimed); train: configs[2]/[3], one optimiser step of "
                          "trainer.py / trainer_multi.py per bench step (batch 4 of 256x256 per GPU, DDP over RCCL)")
+    ap.add_argument("--eager-training", action="store_true",
+                    help="--workload train: issue every launch of a step from Python instead of replaying captured hipGraphs")
     ap.add_argument("--no-extra-workloads", action="store_true",
                     help="N=1 encode run: skip the short decode and training-step measurements added to the JSON line")
     ap.add_argument("--strict-parity", action="store_true",
@@ -504,12 +514,21 @@ def main():
     def conv_roofline(i_n, p_n, precision):
         eng = p_n.engine()
         eng.profile = {}
-        dpb = {"ref_frame": i_n.compress(seq[0], q_i)["x_hat"], "ref_feature": None, "ref_y": None, "ref_mv_y": None}
-        dpb = p_n.compress(seq[1], dpb, q_mv, q_y)["dpb"]
+        dpb0 = {"ref_frame": i_n.compress(seq[0], q_i)["x_hat"].clone(), "ref_feature": None, "ref_y": None, "ref_mv_y": None}
+        dpb = p_n.compress(seq[1], dpb0, q_mv, q_y)["dpb"]
         views = p_n.compress(seq[2], dpb, q_mv, q_y)["_views"]
         torch.cuda.synchronize(dev)
         prof = eng.collect_profile()
         eng.profile = None
+        # the HBM-bound kernels, timed in a second pass WITHOUT the side stream (the feature pyramid's convolutions
+        # would otherwise run beside the warps and resamplers and lengthen them): every launch by itself
+        eng.profile_hbm = {}
+        fork, p_n.fork_features = p_n.fork_features, False
+        dpb = p_n.compress(seq[1], dpb0, q_mv, q_y)["dpb"]
+        p_n.compress(seq[2], dpb, q_mv, q_y)
+        hbm = eng.collect_profile_hbm()
+        eng.profile_hbm = None
+        p_n.fork_features = fork
         # fast mode: the 3x3 stride-1 layers whose input segments are multiples of 32 channels (all heavy ones) run on
         # conv_k32 (profile key "...k32"); the few others stay on conv_mfma and are not part of the dominant kernel
         dom_key = "conv3x3s1k32" if precision != "fp32" and "conv3x3s1k32" in prof else "conv3x3s1"
@@ -536,7 +555,12 @@ def main():
                 "power_note": "on all-zero operands (full 2.4 GHz clock, minimal power) the kernel takes 84 % of its random-data "
                               "time (profiles/r03_conv_data_probe_rand_vs_zero.txt): board power costs ~16 %, the rest is the "
                               "kernel's phase structure and HBM write-back (stamps in profiles/r03_conv_k32_stamps.txt); DESIGN.md 4.1",
-                "dominant_profile_key": dom_key}, views
+                "dominant_profile_key": dom_key,
+                # the HBM-bound kernels of the path (warp, resamplers, dual prior, layout), per shape: HIP
+                # events around every launch of the same two P pictures, algorithmic bytes (each operand once) / time,
+                # against the HBM peak of MI355X_MICROARCH.md (8 TB/s; ~6.3 TB/s is what a streaming kernel reaches)
+                "hbm_kernels": sorted(({**h, "frac_of_8_tb_s": None if h["tb_per_s"] is None else round(h["tb_per_s"] / PEAK_HBM_TBS, 3)}
+                                       for h in hbm), key=lambda h: -h["algorithmic_bytes"] * h["launches"])}, views
 
     roofline, views = conv_roofline(i_net, p_net, args.precision)
     planes = picture_planes(p_net, views) if (rank == 0 and world == 1 and not args.no_cpu_baseline) else None

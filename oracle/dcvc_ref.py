@@ -252,10 +252,13 @@ def dual_prior(w, prior_name, y, means, scales, qstep):
     u0, u1 = means.chunk(2, 1)
     r00, q00, h00, sh00 = _masked(y0, s0, u0, m0)
     r11, q11, h11, sh11 = _masked(y1, s1, u1, m1)
-    s0, u0, s1, u1 = three_convs(w, prior_name, torch.cat((h00, h11, means, scales, qstep), 1)).chunk(4, 1)
+    sp_in = torch.cat((h00, h11, means, scales, qstep), 1)
+    sp_out = three_convs(w, prior_name, sp_in)
+    s0, u0, s1, u1 = sp_out.chunk(4, 1)
     r01, q01, h01, sh01 = _masked(y0, s0, u0, m1)
     r10, q10, h10, sh10 = _masked(y1, s1, u1, m0)
     return {
+        "sp_in": sp_in, "sp_out": sp_out,  # (input / output of the spatial prior: gradient diagnostics)
         "y_res": torch.cat((r00 + r01, r11 + r10), 1),
         "y_q": torch.cat((q00 + q01, q11 + q10), 1),
         "y_hat": torch.cat((h00 + h01, h11 + h10), 1) * qstep,
@@ -484,7 +487,9 @@ def dmc_analysis(w, x, dpb, mv_y_q_scale, y_q_scale):
     ref_y = dpb.get("ref_y")
     if ref_y is None:
         ref_y = torch.zeros_like(y)
-    qs, sc, mu = three_convs(w, "y_prior_fusion", torch.cat((temporal, hier, ref_y), 1)).chunk(3, 1)
+    o["y_fusion"] = three_convs(w, "y_prior_fusion", torch.cat((temporal, hier, ref_y), 1))
+    qs, sc, mu = o["y_fusion"].chunk(3, 1)
+    o["y_in"] = y
     o["y"] = dual_prior(w, "y_spatial_prior", y, mu, sc, qs)
     o["y_hat"] = o["y"]["y_hat"] * q_y
     o["ctxdec"] = contextual_decoder(w, o["y_hat"], c2, c3)

@@ -75,6 +75,14 @@ def main():
             go = go.double()
             cells.append(f"|ref| {float(go.norm()):9.3e} rel {float((gg - go).norm() / (go.norm() + 1e-30)):8.2e}".rjust(40))
         print(f"{term:10s} " + " ".join(cells) + f"   loss rel {abs(lg.item() - lo.item()) / abs(lo.item()):.1e}")
+        if term == os.environ.get("PROBE_LIST_TERM", "bpp_y"):  # every tensor this term reaches, in module order
+            for n, prm in params.items():
+                go, gg = w[n].grad, prm.grad
+                if go is None or gg is None or float(go.norm()) == 0.0:
+                    continue
+                gg, go = gg.cpu().double(), go.double()
+                print(f"      {n:60s} |ref| {float(go.norm()):9.3e}  rel {float((gg - go).norm() / go.norm()):8.2e}  "
+                      f"norm ratio {float(gg.norm() / go.norm()):.4f}")
 
 
 if __name__ == "__main__":

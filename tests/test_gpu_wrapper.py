@@ -158,6 +158,51 @@ def test_training_step_inside_forward_matches_oracle_gradients(method):
     model.dmc._noise_override = None
 
 
+@pytest.mark.parametrize("precision", ["fp32", "fp16x3"])
+def test_graphed_training_step_matches_the_eager_one(precision):
+    """DMC.graph_training (round 4): a training picture replayed from two captured hipGraphs (forward, reverse pass)
+    holds exactly the launches the eager autograd node issues, so four `single_multi` steps with AdamW -- the first
+    after an "I picture" (empty DPB: one pair of graphs), three with the full DPB (a second pair, replayed) -- must
+    leave BIT-IDENTICAL losses, DPBs and parameters.  The noise draws are shared through static device tensors."""
+    from vcm_ts_amd.dcvc_hem import build_model, make_cfg
+
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(9)
+    clip = torch.rand(2, 5, 3, 64, 64, generator=g).to(dev)
+    noises = [{k: (torch.rand(s, generator=g) - 0.5) for k, s in (("y", (2, 96, 4, 4)), ("mv_y", (2, 64, 4, 4)), ("z", (2, 64, 1, 1)),
+                                                               ("mv_z", (2, 64, 1, 1)))} for _ in range(4)]
+    runs = {}
+    for graphed in (False, True):
+        model = build_model(make_cfg(lambdas=LAMBDAS), precision=precision).to(dev).train()
+        model.activate_modules_all()
+        model.dmc.graph_training = graphed
+        static = {k: torch.zeros_like(v, device=dev) for k, v in noises[0].items()}
+        model.dmc._noise_override = static
+        opt = torch.optim.AdamW(model.parameters(), lr=1e-4, betas=(0.9, 0.99), fused=True)
+        dpb = {"ref_frame": clip[:, 0], "ref_feature": None, "ref_y": None, "ref_mv_y": None}
+        losses, recs = [], []
+        for t in range(1, 5):
+            for k, v in noises[t - 1].items():
+                static[k].copy_(v)
+            opt.zero_grad()
+            r = model("single_multi", clip[:, t], clip[:, t], "mse", ["bpp"], perceptual_loss=False, dpb=dpb)
+            r["loss_to_opt"].backward()
+            opt.step()
+            dpb = r["dpb"]
+            losses.append(r["loss_to_opt"].detach().clone())
+            recs.append(dpb["ref_frame"].detach().clone())
+        runs[graphed] = (torch.stack(losses), recs, {k: v.detach().clone() for k, v in model.dmc.named_parameters()})
+        if graphed:
+            fgs = list(model.dmc._frame_graphs.values())
+            assert len(fgs) == 2 and not any(f.busy for f in fgs)   # empty-DPB picture, full-DPB picture
+        model.dmc._noise_override = None
+    assert torch.equal(runs[True][0], runs[False][0]), (runs[True][0], runs[False][0])
+    for a, b in zip(runs[True][1], runs[False][1]):
+        assert torch.equal(a, b)
+    for k, v in runs[False][2].items():
+        assert torch.equal(runs[True][2][k], v), k
+
+
 def test_cascade_multi_backward_and_checkpoint_round_trip(tmp_path):
     """trainer_multi.py's cascade step (train_multi.py:245-258): the caller back-propagates
     `loss_to_opt` of `cascade_multi` itself; gradients equal the oracle's for the same two chained

@@ -3,7 +3,7 @@
 # bench command, plus stats / traffic of both 3x3 kernels through the probe.  Writes under gpurun_out/prof_rNN.
 # usage: tools/profile_round.sh r02
 set -u
-R=${1:-r03}
+R=${1:-r04}
 OUT=gpurun_out/prof_$R
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
@@ -20,6 +20,7 @@ rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT -o probewrite -- python3 tools
 
 # summaries (small text / JSON) -- the databases are too big to travel back
 python3 tools/rocprof_summary.py $OUT/stats1_results.db > $OUT/${R}_bench_gop_streams_1_kernel_stats.txt
+python3 tools/rocprof_hbm.py $OUT/stats1_results.db $OUT/stats1.log > $OUT/${R}_hbm_kernels.txt
 python3 tools/rocprof_summary.py $OUT/stats2_results.db > $OUT/${R}_bench_gop_streams_2_kernel_stats.txt
 python3 tools/rocprof_pmc.py $OUT/fetch_results.db FETCH_SIZE > $OUT/${R}_fp16x3_pmc_fetch_size.txt
 python3 tools/rocprof_pmc.py $OUT/write_results.db WRITE_SIZE > $OUT/${R}_fp16x3_pmc_write_size.txt

@@ -992,8 +992,15 @@ __global__ void scale_bits_bwd_kernel(const float *__restrict__ yv, const float 
     const float b = fminf(fmaxf(s_raw, 1e-5f), 1e10f);
     const float t1 = y + 0.5f, t0 = y - 0.5f;
     const float s1 = sgn(t1), s0 = sgn(t0);
-    const float e1 = expf(-fabsf(t1) / b), e0 = expf(-fabsf(t0) / b);
-    const float F1 = 0.5f - 0.5f * s1 * expm1f(-fabsf(t1) / b), F0 = 0.5f - 0.5f * s0 * expm1f(-fabsf(t0) / b);
+    // torch.autograd differentiates expm1 as grad * (result + 1) (derivatives.yaml), i.e. with exp(u) REBUILT from the
+    // fp32 value of expm1(u): for u << 0 that value sits on the 6e-8 grid next to -1 and the rebuilt exponential is a
+    // multiple of 6e-8 (zero below 3e-8) instead of the tiny true one.  With bits = -log2(p + 1e-5) the factor in front is
+    // up to 1.4e5, so those tails matter: the analytic exp(u) used here until round 3 made the rate gradients of the
+    // hyper-prior path 2-8 % LARGER than the reference's (tests/diag/forced_grad_probe.py, same symbols on both sides).
+    // The reference's arithmetic is the contract, so the kernel rebuilds the exponential the same way.
+    const float m1 = expm1f(-fabsf(t1) / b), m0 = expm1f(-fabsf(t0) / b);
+    const float e1 = m1 + 1.0f, e0 = m0 + 1.0f;
+    const float F1 = 0.5f - 0.5f * s1 * m1, F0 = 0.5f - 0.5f * s0 * m0;
     const float p = F1 - F0;
     const float bits = (-1.0f * logf(p + 1e-5f)) / 0.6931471805599453f;
     float gb = (bits >= 0.f || up < 0.f) ? up : 0.f;          // LowerBound(bits, 0) backward

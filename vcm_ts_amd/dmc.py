@@ -117,6 +117,7 @@ class CodecBase(nn.Module):
         self._chan_cache, self._stage_bufs, self._stage_flip, self._stage_owner = {}, {}, 0, {}
         self._dcoder, self._dc_active, self._dc_stream, self._dc_done = None, False, None, None
         self._graphs = {}
+        self._frame_graphs = {}
         self._fork_stream = None
 
     # -- plumbing ------------------------------------------------------------------------
@@ -385,6 +386,7 @@ class CodecBase(nn.Module):
         e.dual_prior("enc", 1, spatial=spatial, sym=sym[1], idx=idx[1], out=out, q_basic=q_basic, q_scale=q_scale,
                      **common)
         r["sym"], r["idx"] = sym, idx
+        r["params"], r["spatial"] = params, spatial  # (views, for gradient diagnostics)
         return r
 
     def _dual_prior_decode(self, tag, fusion: View, prior_name, out: View, q_basic, q_scale):
@@ -422,6 +424,9 @@ class _FrameFn(torch.autograd.Function):
     def forward(ctx, model, x, rf, rfeat, ry, rmv, qm, qy, *params):
         from .grad import Tape
 
+        # outputs the caller's loss does not use (the DPB in the `single` modes, rate terms that are switched off) arrive
+        # in backward as None instead of as zero tensors that would be transposed into gradient buffers for nothing
+        ctx.set_materialize_grads(False)
         tape = Tape(model.engine())
         dpb_in = dict(zip(_FrameFn.DPB_KEYS, (rf, rfeat, ry, rmv)))
         tape.dpb_grad = {k for k, need in zip(_FrameFn.DPB_KEYS, ctx.needs_input_grad[2:6]) if need}
@@ -471,6 +476,129 @@ class _FrameFn(torch.autograd.Function):
             g_in.append(None if gv is None else e.to_nchw(gv))
         ctx.tape = None
         return (None, None, *g_in, gqm, gqy, *grads)
+
+
+class _FrameGraph:
+    """One training picture as TWO captured hipGraphs -- the recorded forward and the tape's reverse pass -- over static
+    buffers (round 4).  A batch-4 256x256 step is ~1400 launches of 5-50 us each; issued from Python
+    the host needs as long to enqueue them as the GPU to run them (GPU busy 60 % of a step,
+    profiles/r03_gpu_timeline_train.txt).  Replayed, the same launches with the same arguments in the same order cost the
+    host two calls.  Nothing about the arithmetic changes: the graphs hold exactly the launches _FrameFn would issue
+    (test_graphed_training_step_matches_the_eager_one).
+
+    What is static: the picture, the DPB entries, the q-scales and the six upstream gradients are copied into fixed
+    buffers before a replay; every activation / gradient buffer the tape allocates lives in the graphs' private pool;
+    parameter gradients are slices of one flat buffer (one fill, one copy out); the filters are re-packed from the live
+    parameters by the plan launch at the head of the forward graph, so optimiser steps between replays are seen.
+    Used only when at most one picture's tape is alive at a time (the `single*` modes: DPB detached) -- DMC._forward_train
+    falls back to the eager node otherwise."""
+
+    SUMS = ("bits_mv_y", "bits_mv_z", "bits_y", "bits_z", "sq", "me_sq")
+
+    def __init__(self, model, x, dpb, qm, qy, params):
+        from .grad import Tape
+
+        e, dev = model.engine(), model.device
+        self.model, self.params, self.busy = model, params, False
+        self.x = x.detach().clone(memory_format=torch.contiguous_format)
+        self.dpb = {k: (None if v is None else v.detach().clone()) for k, v in dpb.items()}
+        self.qm, self.qy = qm.detach().clone(), qy.detach().clone()
+        N = x.shape[0]
+        self.up = {k: torch.zeros(N, dtype=torch.float32, device=dev) for k in self.SUMS}
+        self.offsets, total = {}, 0
+        for p in params:
+            if p.requires_grad:
+                self.offsets[id(p)] = total
+                total += (p.numel() + 3) // 4 * 4
+        self.flat = torch.zeros(max(total, 4), dtype=torch.float32, device=dev)
+
+        def forward():
+            tape = Tape(e)
+            tape.dpb_grad = set()
+            tape.parena = (self.flat, self.offsets)
+            o, sums = model._train_frame(tape, self.x, self.dpb, self.qm, self.qy)
+            return tape, o, sums
+
+        def backward(tape):
+            self.flat.zero_()
+            tape.up.update(self.up)
+            tape.backward()
+
+        # two eager passes first: every lazily created object (packed filters incl. the transposed ones of the data
+        # gradient, the packing plan -- rebuilt with a blocking call whenever a pass added filters --, scratch buffers,
+        # kernel attributes) must exist before capture, where nothing may synchronise
+        side = torch.cuda.Stream(dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.no_grad(), torch.cuda.stream(side):
+            for _ in range(2):
+                tape, _, _ = forward()
+                backward(tape)
+                del tape
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        self.fwd = torch.cuda.CUDAGraph()
+        with torch.no_grad(), torch.cuda.graph(self.fwd):
+            self.tape, o, sums = forward()
+        self.sums = tuple(sums[k] for k in self.SUMS)
+        d = model._dpb_out(o)
+        self.dpb_out = tuple(d[k] for k in _FrameFn.DPB_KEYS)
+        self.bwd = torch.cuda.CUDAGraph()
+        with torch.no_grad(), torch.cuda.graph(self.bwd, pool=self.fwd.pool()):
+            backward(self.tape)
+        self.dq = {k: self.tape.q[k]["dq_scale"] for k in ("mv", "y")}
+
+    def load(self, x, dpb, qm, qy):
+        self.x.copy_(x)
+        for k, v in self.dpb.items():
+            if v is not None:
+                v.copy_(dpb[k])
+        self.qm.copy_(qm)
+        self.qy.copy_(qy)
+
+
+class _GraphedFrameFn(torch.autograd.Function):
+    """_FrameFn with the launches replayed from a _FrameGraph: same inputs, same outputs, same gradients."""
+
+    @staticmethod
+    def forward(ctx, fg, x, rf, rfeat, ry, rmv, qm, qy, *params):
+        ctx.set_materialize_grads(False)
+        fg.load(x, dict(zip(_FrameFn.DPB_KEYS, (rf, rfeat, ry, rmv))), qm, qy)
+        fg.fwd.replay()
+        fg.busy = True
+        ctx.fg, ctx.q_shapes = fg, (qm.shape, qy.shape)
+        # (copies: the static buffers are overwritten by the next replay, callers keep reconstructions across steps)
+        return tuple(t.clone() for t in fg.sums) + tuple(t.clone() for t in fg.dpb_out)
+
+    @staticmethod
+    def backward(ctx, *g):
+        fg = ctx.fg
+        if fg is None or not fg.busy:
+            raise RuntimeError("this frame's graph was already consumed (retain_graph is not supported)")
+        if any(t is not None for t in g[6:]):
+            raise RuntimeError("graph-replayed training pictures carry no gradient through the DPB (detach it, or set "
+                               "DMC.graph_training = False for the cascade modes)")
+        for name, t in zip(fg.SUMS, g[:6]):
+            if t is None:
+                fg.up[name].zero_()
+            else:
+                fg.up[name].copy_(t.detach().reshape(-1))
+        fg.bwd.replay()
+        fg.busy, ctx.fg = False, None
+        out = fg.flat.clone()  # one copy out; the per-parameter gradients are views of it
+        grads = [out[fg.offsets[id(p)] : fg.offsets[id(p)] + p.numel()].view(p.shape) if (need and id(p) in fg.offsets) else None
+                 for p, need in zip(fg.params, ctx.needs_input_grad[8:])]
+
+        def qgrad(key, shape, need):
+            if not need:
+                return None
+            n = 1
+            for s_ in shape:
+                n *= s_
+            t = fg.dq[key]
+            return (t.sum() if n == 1 else t.clone()).reshape(shape)
+
+        return (None, None, None, None, None, None, qgrad("mv", ctx.q_shapes[0], ctx.needs_input_grad[6]),
+                qgrad("y", ctx.q_shapes[1], ctx.needs_input_grad[7]), *grads)
 
 
 class DMC(CodecBase):
@@ -594,7 +722,7 @@ class DMC(CodecBase):
         return dict(N=N, H=H, W=W, x3=x3, recon=recon, feature=feature, y_hat=y_hat, mv_y_hat=mv_y_hat,
                     warp_frame=warp_frame, r_mv=r_mv, r_y=r_y, mv_z_hat=mv_z_hat, z_hat=z_hat, sym_mv_z=sym_mv_z,
                     sym_z=sym_z, est_mv=est_mv, mv_hat=mv_hat, c1=c1, c2=c2, c3=c3, y=y, mv_y=mv_y, z=z, mv_z=mv_z,
-                    q_mv=q_mv, q_y=q_y, dv=dv)
+                    q_mv=q_mv, q_y=q_y, dv=dv, fusion_y=fusion)
 
     @staticmethod
     def _dpb_out(o):
@@ -653,6 +781,29 @@ class DMC(CodecBase):
         finally:
             e.tape = None
 
+    # Replay training pictures from captured hipGraphs (_FrameGraph).  Opt-in: the caller promises the `single` training
+    # recursion (one picture's backward before the next picture's forward, DPB detached), which is what trainer.py /
+    # trainer_multi.py run in the stages bench.py times; anything else falls back to the eager node by itself.
+    graph_training = False
+
+    def _frame_graph(self, x, dpb_t, qm, qy, params):
+        """The _FrameGraph for this call, or None when the call cannot be replayed (then the eager _FrameFn runs)."""
+        static_noise = self._noise_override is None or all(t.is_cuda and t.dtype == torch.float32 for t in self._noise_override.values())
+        if (not static_noise or self._forced is not None or not torch.is_grad_enabled()
+                or any(v is not None and v.requires_grad for v in dpb_t) or x.requires_grad
+                or torch.cuda.is_current_stream_capturing()):
+            return None
+        key = (tuple(x.shape), tuple(None if v is None else tuple(v.shape) for v in dpb_t), tuple(qm.shape), tuple(qy.shape),
+               tuple((id(p), p.requires_grad, p.data_ptr()) for p in params), self.engine().precision,
+               None if self._noise_override is None else tuple(t.data_ptr() for t in self._noise_override.values()))
+        fg = self._frame_graphs.get(key)
+        if fg is None:
+            if len(self._frame_graphs) >= 4:
+                self._frame_graphs.pop(next(iter(self._frame_graphs)))
+            fg = _FrameGraph(self, x, dict(zip(_FrameFn.DPB_KEYS, dpb_t)), qm, qy, params)
+            self._frame_graphs[key] = fg
+        return None if fg.busy else fg
+
     def _forward_train(self, x, dpb, mv_y_q_scale, y_q_scale):
         qm = self.P("mv_y_q_scale") if mv_y_q_scale is None else mv_y_q_scale
         qy = self.P("y_q_scale") if y_q_scale is None else y_q_scale
@@ -663,8 +814,12 @@ class DMC(CodecBase):
         # only when it is the one passed in)
         skip = ("feature_adaptor_P." if dpb.get("ref_feature") is None else "feature_adaptor_I.")
         params = [p for n, p in self._pmap.items() if not n.startswith(skip) and n not in ("mv_y_q_scale", "y_q_scale")]
-        outs = _FrameFn.apply(self, x, dpb.get("ref_frame"), dpb.get("ref_feature"), dpb.get("ref_y"), dpb.get("ref_mv_y"),
-                              qm, qy, *params)
+        dpb_t = tuple(dpb.get(k) for k in _FrameFn.DPB_KEYS)
+        fg = self._frame_graph(x, dpb_t, qm, qy, params) if self.graph_training else None
+        if fg is not None:
+            outs = _GraphedFrameFn.apply(fg, x, *dpb_t, qm, qy, *params)
+        else:
+            outs = _FrameFn.apply(self, x, *dpb_t, qm, qy, *params)
         bits_mv_y, bits_mv_z, bits_y, bits_z, sq, me_sq, recon, feature, y_hat, mv_y_hat = outs
         pix = x.shape[2] * x.shape[3]
         bpp_y, bpp_z, bpp_mv_y, bpp_mv_z = bits_y / pix, bits_z / pix, bits_mv_y / pix, bits_mv_z / pix

@@ -41,6 +41,7 @@ class Tape:
         self.up = {}          # name of a per-sample output sum -> upstream gradient (N,) tensor
         self.pool = []        # zero-filled chunks the gradient buffers are carved from (one memset each)
         self.pool_left = 0
+        self.parena = None    # (flat zero-filled tensor, {id(parameter): offset}) when parameter gradients share one buffer
 
     # ------------------------------------------------------------------ bookkeeping
     def mark_const(self, v: View):
@@ -80,7 +81,13 @@ class Tape:
         """zero=False: the caller's kernel writes (=) every element, so no fill launch is spent."""
         g = self.pgrads.get(id(p))
         if g is None:
-            g = (torch.zeros_like if zero else torch.empty_like)(p, memory_format=torch.contiguous_format)
+            if self.parena is not None and id(p) in self.parena[1]:
+                # graph mode (dmc._FrameGraph): every parameter gradient is a slice of ONE flat buffer that the backward
+                # graph zeroes with a single fill and hands out with a single copy
+                off = self.parena[1][id(p)]
+                g = self.parena[0][off : off + p.numel()].view(p.shape)
+            else:
+                g = (torch.zeros_like if zero else torch.empty_like)(p, memory_format=torch.contiguous_format)
             self.pgrads[id(p)] = g
         return g
 
@@ -195,7 +202,10 @@ class Tape:
             ready.record(main)
             side.wait_event(ready)
             if need_pro:
-                dpre.base.record_stream(side)  # a temporary: keep the allocator from recycling it early
+                if torch.cuda.is_current_stream_capturing():
+                    self.keep.append(dpre.base)  # (a captured pass keeps its temporaries: the graph owns them anyway)
+                else:
+                    dpre.base.record_stream(side)  # a temporary: keep the allocator from recycling it early
             wstream = C.c_void_p(side.cuda_stream)
             o = off
             for si, s in enumerate(srcs):
