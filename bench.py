@@ -259,10 +259,11 @@ def train_workload(args, dev, rank, world):
     prec = "fp32" if args.precision == "fp32" else "fp16x3"
     model = build_model(make_cfg(lambdas=(85.0, 170.0, 380.0, 840.0)), precision=prec).to(dev).train()
     model.activate_modules_all()
-    # the `single` recursion (one picture's backward before the next picture's forward): the picture's launches are
-    # replayed from captured hipGraphs (same launches, same results: tests/test_gpu_wrapper.py); --eager-training
-    # issues them from Python as rounds 1-3 did
-    model.dmc.graph_training = not getattr(args, "eager_training", False)
+    # --graph-training: replay each picture's launches from captured hipGraphs (DMC.graph_training; same launches, same
+    # results: tests/test_gpu_wrapper.py).  Measured in round 4 it is SLOWER here (30.4 ms against 26.2 ms per step): the
+    # step is bound by the GPU's own per-kernel gaps, not by the host, and a replayed graph runs its kernel nodes one
+    # after the other, losing the overlap of the weight-gradient stream with the data-gradient chain
+    model.dmc.graph_training = bool(getattr(args, "graph_training", False))
     net = model
     if torch.distributed.is_available() and torch.distributed.is_initialized():
         # also with ONE rank under a launcher: DistributedDataParallel's bucketed all-reduce then runs over RCCL
@@ -367,8 +368,9 @@ def main():
                          "encode: BASELINE configs[1] (the headline metric, default); decode: the same GOPs through "
                          "decompress (payloads made once, untimed); train: configs[2]/[3], one optimiser step of "
                          "trainer.py / trainer_multi.py per bench step (batch 4 of 256x256 per GPU, DDP over RCCL)")
-    ap.add_argument("--eager-training", action="store_true",
-                    help="--workload train: issue every launch of a step from Python instead of replaying captured hipGraphs")
+    ap.add_argument("--graph-training", action="store_true",
+                    help="--workload train: replay every picture from captured hipGraphs instead of issuing its launches from "
+                         "Python (same results; slower on this runtime, see DESIGN.md 4b)")
     ap.add_argument("--no-extra-workloads", action="store_true",
                     help="N=1 encode run: skip the short decode and training-step measurements added to the JSON line")
     ap.add_argument("--strict-parity", action="store_true",

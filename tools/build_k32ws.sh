@@ -5,7 +5,7 @@
 # usage: tools/build_k32ws.sh [extra -D flags for the experiment]   (after `make -C vcm_ts_amd/csrc`)
 set -e
 C=vcm_ts_amd/csrc; O=tools/probes/variants; mkdir -p $O/obj
-F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -Iinclude"
+F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Iinclude"
 NOPK="-Xclang -target-feature -Xclang -packed-fp32-ops"
 one() {  # name source extra-flags...
   local name=$1 src=$2; shift 2

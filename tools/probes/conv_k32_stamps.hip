@@ -13,7 +13,7 @@ __device__ unsigned long long *g_k32_stamps;
             if ((i) == 10) s_[61] = __builtin_amdgcn_s_memrealtime();                                                  \
         }                                                                                                              \
     } while (0)
-#include "../../vcm_ts_amd/csrc/conv_k32.hip"
+#include "conv_k32_dev.hip"  // generated: product kernel + conv_k32_dev_switches.patch (Makefile)
 
 extern "C" int k32_stamps_set(unsigned long long *buf) {
     return hipMemcpyToSymbol(HIP_SYMBOL(g_k32_stamps), &buf, sizeof(buf)) == hipSuccess ? 0 : -1;

@@ -37,27 +37,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
-// developer probes (tools/probes/conv_k32_stamps.hip) define K32_STAMP to record s_memtime at phase boundaries;
-// in the product library it expands to nothing
-#ifndef K32_STAMP
-#define K32_STAMP(i)
-#endif
-// developer ablation builds (tools/build_variant.sh ... -DK32_ABLATE=n): 1 = no MFMAs (fragment reads kept alive),
-// 2 = no fragment reads and no MFMAs, 4 = no epilogue stores / residual loads.  0 in the product.
-#ifndef K32_ABLATE
-#define K32_ABLATE 0
-#endif
-// patch staging variants (developer A/B, tools/ab_probe.py): bit 0 = out-of-picture slots are read through a buffer
-// descriptor with an out-of-range offset (the hardware returns zeros: no select per value), bit 1 = the input activation
-// as max(s, s * slope) on the scaled value (two operations per value instead of multiply + compare + select)
-#ifndef K32_STAGE
-#define K32_STAGE 3
-#endif
-// epilogue variant (developer A/B): 1 = residual loads and output stores through buffer descriptors (scalar base + 32-bit
-// offset, masked lanes get an out-of-range offset: loads return zeros, stores are dropped -- no branch per access)
-#ifndef K32_EPI
-#define K32_EPI 1
-#endif
+// (Developer builds -- s_memtime stamps at the phase boundaries, ablation variants without MFMAs / fragment reads /
+// stores, the staging and epilogue alternatives measured in round 3 -- are produced by applying
+// tools/probes/conv_k32_dev_switches.patch to a COPY of this file: tools/probes/Makefile, tools/build_variant.sh.)
 
 namespace {
 
@@ -157,17 +139,16 @@ __global__ __launch_bounds__(64 * NWAVE, NWAVE / 2) void conv_k32(const K32 a) {
     auto ld16 = [](const void *base, unsigned byte_off) __attribute__((always_inline)) {
         return *(const f32x4 *)((const char *)base + byte_off);
     };
-    unsigned inpic = 0;  // bit u: slot u of the patch in the staging registers lies inside the picture
     auto load_patch = [&](const Cursor &k) {
         const unsigned cs4 = (unsigned)a.seg_cs[k.s] * 4u;  // bytes per pixel of this segment (< 2^24)
         const char *sp = (const char *)(a.seg_ptr[k.s] + (size_t)img * a.H * a.W * a.seg_cs[k.s] + k.c0);
         int t = tid;
         asm volatile("" : "+v"(t));  // (opaque: keeps the compiler from hoisting the slot arithmetic back out of the loop)
         const unsigned lane_off = (t & 7) * 16u;
-        inpic = 0;
-        // (K32_STAGE & 1) the image as a raw buffer: an offset at or beyond num_records reads as zeros
+        // the image as a raw buffer: an offset at or beyond num_records reads as zeros (no select per value for the
+        // out-of-picture slots of the halo)
         const unsigned img_bytes = (unsigned)(a.H * a.W) * cs4;  // (< 2^32: dcvc_conv2d_k32 checks)
-        [[maybe_unused]] const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)sp, 0, (int)img_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)sp, 0, (int)img_bytes, 0x00020000);
 #pragma unroll
         for (int u = 0; u < NP; ++u) {
             const int i = t + u * NTH;
@@ -177,13 +158,8 @@ __global__ __launch_bounds__(64 * NWAVE, NWAVE / 2) void conv_k32(const K32 a) {
             // (bitwise on purpose: && would turn every slot into a branch)
             const unsigned ok = (unsigned)(tid + u * NTH < PH * PW * 8) & (unsigned)((unsigned)gy < (unsigned)a.H) &
                                 (unsigned)((unsigned)gx < (unsigned)a.W);
-            if (K32_STAGE & 1) {
-                const unsigned off = ok ? __umul24((unsigned)(gy * a.W + gx), cs4) + lane_off : img_bytes;
-                rp[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, 0, 0));
-            } else {
-                rp[u] = ld16(sp, __umul24((unsigned)(gy * a.W + gx) & (0u - ok), cs4) + lane_off);
-                inpic |= ok << u;
-            }
+            const unsigned off = ok ? __umul24((unsigned)(gy * a.W + gx), cs4) + lane_off : img_bytes;
+            rp[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, 0, 0));
         }
     };
     auto store_patch = [&]() {
@@ -191,30 +167,17 @@ __global__ __launch_bounds__(64 * NWAVE, NWAVE / 2) void conv_k32(const K32 a) {
         for (int u = 0; u < NP; ++u) {
             const int i = tid + u * NTH;
             if (i < PH * PW * 8) {
-                f32x4 v = rp[u];
-                if (!(K32_STAGE & 1)) v = ((inpic >> u) & 1u) ? v : (f32x4){0.f, 0.f, 0.f, 0.f};
-                f32x4 sv;
-                if (K32_STAGE & 2) {
-                    // LeakyReLU on the scaled value: max(s, s * slope) == 8 * (v > 0 ? v : v * slope) for 0 <= slope <= 1
-                    // (a power-of-two scale commutes with the rounding of v * slope; dcvc_conv2d_k32 checks the slope)
-                    sv = v * ACT_SCALE;
-                    if (a.in_act) {
+                // LeakyReLU on the scaled value: max(s, s * slope) == 8 * (v > 0 ? v : v * slope) for 0 <= slope <= 1
+                // (a power-of-two scale commutes with the rounding of v * slope; dcvc_conv2d_k32 checks the slope)
+                f32x4 sv = rp[u] * ACT_SCALE;
+                if (a.in_act) {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {  // (one v_max_f32: fmaxf would add a NaN-quieting operation per value)
-                            const float t = sv[e] * a.in_slope;
-                            float r;
-                            asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(sv[e]), "v"(t));
-                            sv[e] = r;
-                        }
+                    for (int e = 0; e < 4; ++e) {  // (one v_max_f32: fmaxf would add a NaN-quieting operation per value)
+                        const float t = sv[e] * a.in_slope;
+                        float r;
+                        asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(sv[e]), "v"(t));
+                        sv[e] = r;
                     }
-                } else {
-                    if (a.in_act) {
-                        v[0] = act(v[0], a.in_slope);
-                        v[1] = act(v[1], a.in_slope);
-                        v[2] = act(v[2], a.in_slope);
-                        v[3] = act(v[3], a.in_slope);
-                    }
-                    sv = v * ACT_SCALE;
                 }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) sv[e] = __builtin_amdgcn_fmed3f(sv[e], -F16_MAX, F16_MAX);
@@ -245,7 +208,6 @@ __global__ __launch_bounds__(64 * NWAVE, NWAVE / 2) void conv_k32(const K32 a) {
     };
 
     auto mfma_step = [&](int st) __attribute__((always_inline)) {
-        if (K32_ABLATE & 2) return;
         const int a_st = st * PW * REC;  // filter row ky = st
 #pragma unroll
         for (int tl = 0; tl < TPS; ++tl) {  // kx = tl
@@ -260,13 +222,6 @@ __global__ __launch_bounds__(64 * NWAVE, NWAVE / 2) void conv_k32(const K32 a) {
             for (int n = 0; n < NTW; ++n) {
                 bh[n] = *(const f16x8 *)&wl[b_base + ((tl * 2 + 0) * 4 * BN + n * 16) * 4];
                 bl[n] = *(const f16x8 *)&wl[b_base + ((tl * 2 + 1) * 4 * BN + n * 16) * 4];
-            }
-            if (K32_ABLATE & 1) {  // keep the fragment reads, drop the matrix work
-#pragma unroll
-                for (int m = 0; m < MT; ++m) asm volatile("" ::"v"(ah[m]), "v"(al[m]));
-#pragma unroll
-                for (int n = 0; n < NTW; ++n) asm volatile("" ::"v"(bh[n]), "v"(bl[n]));
-                continue;
             }
 #pragma unroll
             for (int m = 0; m < MT; ++m)
@@ -287,20 +242,13 @@ __global__ __launch_bounds__(64 * NWAVE, NWAVE / 2) void conv_k32(const K32 a) {
     // hides behind three steps of MFMAs (on all-zero operands, i.e. at the full clock, this kernel takes 85 % of its
     // random-data time -- tools/conv_data_probe.py: stalls, not board power, are the larger part of what bounds it).
     Cursor cur = {0, 0, 0, 0};
-    K32_STAMP(0);
     load_patch(cur);
     load_w(cur);
-    [[maybe_unused]] int stamp_step = 0;
     while (cur.s < a.nseg) {
-        K32_STAMP(1 + 4 * stamp_step);
         __syncthreads();  // every wave is done reading the previous step's LDS
-        K32_STAMP(2 + 4 * stamp_step);
         if (cur.st == 0) store_patch();
         store_w();
-        K32_STAMP(3 + 4 * stamp_step);
         __syncthreads();
-        K32_STAMP(4 + 4 * stamp_step);
-        ++stamp_step;
         Cursor nxt = cur;
         advance(nxt);
         if (cur.st == 0) {
@@ -359,12 +307,11 @@ __global__ __launch_bounds__(64 * NWAVE, NWAVE / 2) void conv_k32(const K32 a) {
     const char *res2_b = a.res2 ? (const char *)(a.res2 + img_pix * a.res2_cs) : nullptr;
     char *out_b = (char *)(a.out + img_pix * a.out_cs);
     f32x4 rv[MT][NTW];
-    K32_STAMP(57);
-    K32_STAMP(58);
-    // (K32_EPI) the output / residual images as raw buffers: offset == num_records is out of range
+    // the output / residual images as raw buffers (scalar base + 32-bit offset; a masked lane gets offset == num_records:
+    // its load returns zeros, its store is dropped -- no branch per access)
     const unsigned out_bytes = (unsigned)(Ho * Wo) * (unsigned)a.out_cs * 4u, res_bytes = (unsigned)(Ho * Wo) * (unsigned)a.res_cs * 4u;
-    [[maybe_unused]] const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc((void *)out_b, 0, (int)out_bytes, 0x00020000);
-    [[maybe_unused]] const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc((void *)res_b, 0, a.res ? (int)res_bytes : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc((void *)out_b, 0, (int)out_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc((void *)res_b, 0, a.res ? (int)res_bytes : 0, 0x00020000);
     if (a.res) {  // (requesting these under the last step's MFMAs was tried, also with the last step peeled off the loop:
                   // the compiler keeps or spills their 32-64 registers; requesting only their cache lines there (LDS-DMA
                   // loads into a sink) made the launch 3 % slower, tools/ab_probe.py)
@@ -373,10 +320,7 @@ __global__ __launch_bounds__(64 * NWAVE, NWAVE / 2) void conv_k32(const K32 a) {
 #pragma unroll
             for (int n = 0; n < NTW; ++n) {
                 const bool ok = (okm >> (m * NTW + n)) & 1u;
-                if (K32_EPI)
-                    rv[m][n] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_res, (int)(ok ? out_off(m, n, a.res_cs) : res_bytes), 0, 0));
-                else
-                    rv[m][n] = ld16(res_b, ok ? out_off(m, n, a.res_cs) : 0u);
+                rv[m][n] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_res, (int)(ok ? out_off(m, n, a.res_cs) : res_bytes), 0, 0));
             }
     }
     // (fused SE squeeze) channel sums per ROW of the tile, so that the result does not depend on how many rows a wave owns
@@ -411,25 +355,21 @@ __global__ __launch_bounds__(64 * NWAVE, NWAVE / 2) void conv_k32(const K32 a) {
                 }
             }
             const bool ok = (okm >> (m * NTW + n)) & 1u;
-            if (K32_EPI && !a.res2 && !a.chan_partial) {
+            if (!a.res2 && !a.chan_partial) {
                 // range guard, always on (two v_max3_f32 per 4 outputs): an output beyond +-8188 would be clamped by
                 // a split-fp16 consumer.  An infinity is caught here; a NaN can only follow one.
                 const float m4 = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
                 vmax = fmaxf(vmax, ok ? m4 : 0.f);
-                if (!(K32_ABLATE & 4))
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) int, v), rs_out,
-                                                           (int)(ok ? out_off(m, n, a.out_cs) : out_bytes), 0, 0);
-                else asm volatile("" ::"v"(v));
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) int, v), rs_out,
+                                                       (int)(ok ? out_off(m, n, a.out_cs) : out_bytes), 0, 0);
             } else if (ok) {
                 if (a.res2) v = ld16(res2_b, out_off(m, n, a.res2_cs)) + v;
                 if (a.chan_partial) csum[m >> 1][n] += v;
                 vmax = fmaxf(vmax, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
-                if (!(K32_ABLATE & 4)) *(f32x4 *)(out_b + out_off(m, n, a.out_cs)) = v;
-                else asm volatile("" ::"v"(v));
+                *(f32x4 *)(out_b + out_off(m, n, a.out_cs)) = v;
             }
         }
     }
-    K32_STAMP(59);
     if (a.status && !(vmax <= ACT_LIMIT)) atomicOr(a.status, DCVC_STATUS_ACT_SATURATED);
     if (a.chan_partial) {
         // SELayer's AdaptiveAvgPool (video_net.py:149-162) rides on the producing convolution: per tile ROW the two
@@ -565,7 +505,7 @@ extern "C" int dcvc_conv2d_k32(const dcvc_conv_args *a, void *stream) {
             (a->res2 && opix * a->res2_cs * 4ull > 0xfffffff0ull))
             return DCVC_E_ARG;
     }
-    if ((K32_STAGE & 2) && a->in_act && !(a->in_slope >= 0.f && a->in_slope <= 1.f)) return DCVC_E_ARG;
+    if (a->in_act && !(a->in_slope >= 0.f && a->in_slope <= 1.f)) return DCVC_E_ARG;  // (store_patch's max(s, s * slope))
     for (int s = 0; s < a->nseg; ++s)  // an image of a segment is addressed with 32-bit byte offsets (and as a raw buffer)
         if ((unsigned long long)a->Hin * a->Win * a->seg[s].cs * 4ull > 0xfffffff0ull) return DCVC_E_ARG;
     k.nseg = a->nseg;

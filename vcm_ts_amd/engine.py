@@ -121,6 +121,7 @@ class Engine:
         # fast mode: weight gradients of stride-1 layers on the bf16 matrix cores (hi + lo operands, three products);
         # DCVC_WGRAD_SPLIT=0 keeps them on the fp32 MFMA
         self.wgrad_split = os.environ.get("DCVC_WGRAD_SPLIT", "1") != "0"
+        self.wgrad_side_stream = sw("DCVC_WGRAD_SIDE", "1") != "0"  # weight gradients on a second stream beside the data-gradient chain
 
     # ------------------------------------------------------------------ memory
     def stream(self):

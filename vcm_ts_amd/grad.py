@@ -101,6 +101,8 @@ class Tape:
         return self.e.fbuf("grad_scratch", n, scratch=True)
 
     def side_stream(self):
+        if not getattr(self.e, "wgrad_side_stream", True):  # (developer A/B: everything on the launch stream)
+            return torch.cuda.current_stream(self.e.device)
         if getattr(self.e, "_wgrad_stream", None) is None:
             self.e._wgrad_stream = torch.cuda.Stream(self.e.device)
         self.used_side = True
