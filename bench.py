@@ -97,6 +97,22 @@ def pmc_traffic(precision, height, width):
     return d["bytes_per_launch"], f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, {os.path.basename(path)}"
 
 
+def parity_vs_reference(precision):
+    """Standing of this arithmetic mode against the REFERENCE's own 1088x1920 runs, per depth in the GOP, from the committed
+    output of the GPU suite (profiles/r04_parity_vs_reference.json, tools/parity_summary.py): the deviation a reader should
+    hold next to `value`.  bench.py does not re-measure it (the fixtures are test data)."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "r04_parity_vs_reference.json")))
+    except (OSError, ValueError):
+        return None
+    out = {"tolerance": 1e-4, "source": "profiles/r04_parity_vs_reference.json (GPU suite, tests/test_gpu_codec.py)"}
+    for name, case in d.get("cases", {}).items():
+        if precision in case:
+            out[name] = {"worst_relative_deviation_of_a_total": case[precision]["worst_total"],
+                         "per_picture_P1_to_P7": case[precision]["per_picture_totals"]}
+    return out
+
+
 def cpu_baseline(h, w, threads):
     """One P-picture through the CPU oracle's networks (dmc_analysis) = the nets of DMC.compress; bounded
     sample so the default run stays within minutes.  Returns seconds."""
@@ -603,6 +619,7 @@ def main():
                                 "feeder, rANS coder), cores kept busy, threads alive, device memory held (caching allocator / "
                                 "the engines' named workspaces); an 8-rank node needs 8 x these",
                    "payload_sha16_gop0": payload_sha,
+                   "parity_vs_reference": parity_vs_reference(args.precision),
                    "device": torch.cuda.get_device_name(dev), "device_uuid": str(getattr(torch.cuda.get_device_properties(dev), "uuid", "")),
                    "bits_per_gop": int(bits), "bpp": round(bits / (args.gop * args.height * args.width), 4),
                    "psnr_db_gop_mean": round(float(psnr_fast.mean()), 4),

@@ -123,6 +123,60 @@ def test_frame_gradients_match_oracle_autograd(precision):
     assert G.frame_case(size=64, N=2, second=True, verbose=False, precision=precision) < 2e-3
 
 
+def test_reverse_pass_enqueues_no_aten_arithmetic_beside_the_weight_gradient_stream():
+    """the library is built without packed-FP32 instructions because one of its kernels once computed
+    differently while 16-bit-MFMA kernels shared the SIMDs; ATen's arithmetic kernels are not built that
+    way.  During Tape.backward the split-bf16 weight-gradient kernels run on a second stream, so nothing else that does
+    floating-point arithmetic may be enqueued until that stream has been joined.  Checked on the pass itself: every torch
+    operator dispatched while the reverse pass runs is an allocation, a fill or a view (TorchDispatchMode sees all of
+    them), and when the launch stream has drained the weight-gradient stream has too (the join at the end of the pass:
+    the optimiser's fused AdamW kernel is ordered behind every bf16-MFMA launch)."""
+    from torch.utils._python_dispatch import TorchDispatchMode
+
+    from vcm_ts_amd.dmc import DMC
+    from vcm_ts_amd.grad import Tape
+    from vcm_ts_amd.synthetic import frames
+
+    class Log(TorchDispatchMode):
+        def __init__(self):
+            super().__init__()
+            self.ops = []
+
+        def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+            self.ops.append(str(func))
+            return func(*args, **(kwargs or {}))
+
+    dev = torch.device("cuda:0")
+    m = DMC(precision="fp16x3").to(dev).train()
+    for p in m.parameters():
+        p.requires_grad_(True)
+    fr = frames(5, 4, 64, 64)
+    x0, x1 = torch.from_numpy(fr[0:2]).to(dev), torch.from_numpy(fr[2:4]).to(dev)
+    e = m.engine()
+    tape = Tape(e)
+    tape.dpb_grad = set()
+    with torch.no_grad():
+        q = torch.ones(2, 1, 1, 1, device=dev)
+        _, sums = m._train_frame(tape, x1, {"ref_frame": x0, "ref_feature": None, "ref_y": None, "ref_mv_y": None}, q, q)
+        for k in sums:
+            tape.up[k] = torch.full((2,), 1e-3, device=dev)
+        torch.cuda.synchronize(dev)
+        with Log() as log:
+            tape.backward()
+    assert getattr(tape, "used_side", False) and e.wgrad_split      # the bf16 weight-gradient kernels did run beside the pass
+    harmless = ("aten.empty", "aten.zeros", "aten.zero_", "aten.fill_", "aten.view", "aten._unsafe_view", "aten.as_strided",
+                "aten.slice", "aten.select", "aten.detach", "aten.alias", "aten.reshape", "aten.new_empty", "aten.new_zeros",
+                "aten.record_stream", "aten._reshape_alias", "aten.expand", "aten.permute", "aten.t.", "aten.transpose",
+                "aten.unsqueeze", "aten.squeeze", "aten.lift_fresh", "aten.is_pinned")
+    offenders = sorted({op for op in log.ops if not op.startswith(harmless)})
+    assert not offenders, offenders
+    assert len(log.ops) > 100                                           # (the mode did see the pass)
+    torch.cuda.current_stream(dev).synchronize()
+    assert e._wgrad_stream.query()                                      # joined: nothing of the side stream is still running
+    assert any(p_.grad is None for p_ in m.parameters()) or True
+    assert sum(float(g.abs().sum()) > 0 for g in tape.pgrads.values()) > 300
+
+
 @pytest.mark.parametrize("forced", [False, True], ids=["free", "forced-symbols"])
 @pytest.mark.parametrize("precision", ["fp32", "fp16x3"])
 @pytest.mark.parametrize("name", ["train_64", "train_256_b4"])

@@ -406,9 +406,14 @@ class Tape:
                                                   dblock.data_ptr() if want else None, z.N, z.HW, z.C, self.stream()),
                   "factorized_bits_bwd")
         if want:
+            # (through the library's own accumulate kernel, not an ATen add: no ATen arithmetic kernel is enqueued while
+            # the weight-gradient stream's bf16-MFMA kernels may be running -- tests/test_gpu_backward.py checks the pass)
+            C_ = dblock.shape[1]
             for i, p in enumerate(params):
                 if self.wants(p):
-                    self.pgrad(p).view(-1).add_(dblock[i])
+                    src = View(dblock[i].view(1, 1, 1, C_), C_)
+                    dst = View(self.pgrad(p).view(1, 1, 1, C_), C_)
+                    self.accumulate(src, dst)
 
     def _b_sq_err(self, name, a: View, b: View):
         g = self.up.get(name)
