@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round profiles of the other workloads and modes (run through gpurun): writes small summaries under gpurun_out/prof_wl
-R=${1:-r02}
+R=${1:-r04}
 OUT=gpurun_out/prof_wl; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
 python3 bench.py --workload train --steps 20 --warmup 5 > $OUT/${R}_bench_train_n1_fp16x3.json 2> $OUT/train.err
