@@ -125,8 +125,9 @@ class GopEncoder:
             yield t
         if prev is not None:
             retire(prev)
-            self.i_net.engine().check_status()  # (everything is retired: these reads find the GPU idle)
-            self.p_net.engine().check_status()
+            if not prev[4]:  # a trailing partial GOP: its pictures have not been looked at yet (a synchronising read;
+                self.i_net.engine().check_status()  # after a whole GOP the snapshot above has already covered everything
+                self.p_net.engine().check_status()  # and nothing is drained here)
         res.update(coded=out, bits=bits, dpb=dpb)
 
     def decode_gop(self, coded, height, width):
