@@ -180,7 +180,7 @@ class Tape:
         if gate is not None:  # d gate(n, c) = sum_pixels dout * res
             dg = self.vec.get(gate.data_ptr())
             if dg is None:
-                dg = torch.zeros_like(gate)
+                dg = self.zeros(gate.numel()).view(gate.shape)  # (from the zeroed pool: no fill launch of its own)
                 self.vec[gate.data_ptr()] = dg
             self.channel_dot(dout, res, dg, over_batch=False, accumulate=True)
         off = 0 if pk.cin_slice is None else pk.cin_slice[0]
@@ -314,9 +314,9 @@ class Tape:
     def qstate(self, qkey, q_basic_param, q_scale, N, Cq):
         q = self.q.get(qkey)
         if q is None:
-            z = lambda: torch.zeros(N * Cq, dtype=torch.float32, device=self.e.device)
+            z = lambda: self.zeros(N * Cq)
             q = dict(param=q_basic_param, q_scale=q_scale, dq_mul=z(), s_div=z(), N=N, C=Cq,
-                     dq_scale=torch.zeros(N, dtype=torch.float32, device=self.e.device))
+                     dq_scale=self.zeros(N))
             self.q[qkey] = q
         return q
 
@@ -400,7 +400,7 @@ class Tape:
         if g is None:
             return
         want = any(self.wants(p) for p in params)
-        dblock = torch.zeros_like(pblock) if want else None
+        dblock = self.zeros(pblock.numel()).view(pblock.shape) if want else None
         dz = self.grad(z)
         lib.check(self.L.dcvc_factorized_bits_bwd(z_bit.ptr, z_bit.cs, pblock.data_ptr(), g.data_ptr(), dz.ptr, dz.cs,
                                                   dblock.data_ptr() if want else None, z.N, z.HW, z.C, self.stream()),
