@@ -118,7 +118,6 @@ class CodecBase(nn.Module):
         self._dcoder, self._dc_active, self._dc_stream, self._dc_done = None, False, None, None
         self._graphs = {}
         self._frame_graphs = {}
-        self._pgrad_layout = {}
         self._fork_stream = None
 
     # -- plumbing ------------------------------------------------------------------------
@@ -429,22 +428,6 @@ class _FrameFn(torch.autograd.Function):
         # in backward as None instead of as zero tensors that would be transposed into gradient buffers for nothing
         ctx.set_materialize_grads(False)
         tape = Tape(model.engine())
-        # every parameter gradient of this picture is a slice of ONE zero-filled buffer: one fill launch instead of one per
-        # tensor whose kernel accumulates (~100 small fills on the critical stream of a batch-4 256x256 step, round 4)
-        key = tuple(id(p) for p in params)
-        lay = model._pgrad_layout.get(key)
-        if lay is None:
-            offsets, total = {}, 0
-            for p in params:
-                if p.requires_grad:
-                    offsets[id(p)] = total
-                    total += (p.numel() + 3) // 4 * 4
-            model._pgrad_layout.clear()
-            lay = model._pgrad_layout[key] = (offsets, total, tuple(p.requires_grad for p in params))
-        if lay[2] == tuple(p.requires_grad for p in params) and lay[1] > 0:
-            tape.parena = (torch.zeros(lay[1], dtype=torch.float32, device=model.device), lay[0])
-        else:
-            model._pgrad_layout.clear()
         dpb_in = dict(zip(_FrameFn.DPB_KEYS, (rf, rfeat, ry, rmv)))
         tape.dpb_grad = {k for k, need in zip(_FrameFn.DPB_KEYS, ctx.needs_input_grad[2:6]) if need}
         o, sums = model._train_frame(tape, x.detach(), {k: (None if v is None else v.detach()) for k, v in dpb_in.items()},
@@ -474,7 +457,7 @@ class _FrameFn(torch.autograd.Function):
         grads = []
         for p, need in zip(ctx.params, ctx.needs_input_grad[8:]):
             g = tape.pgrads.get(id(p)) if need else None
-            grads.append(tape.pgrad(p) if (need and g is None) else g)  # (untouched: its zero slice of the flat buffer)
+            grads.append(torch.zeros_like(p) if (need and g is None) else g)
 
         def qgrad(key, shape, need):
             if not need:
