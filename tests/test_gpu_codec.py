@@ -199,12 +199,12 @@ def test_bench_size_matches_reference_fixture(nets):
     assert xs[0].shape == (1, 3, 1088, 1920)
     # second P picture: at this size and rate (bpp ~6 with random-init weights, 1.4 M symbols per picture) the
     # ties of the first two pictures move single rate COMPONENTS by up to ~3e-4 (bpp_mv_y 2.4e-4 in the exact-fp32
-    # mode).  Total bpp, mse and PSNR of the second P picture: within 1e-4 in the exact mode (3e-6 measured); the
-    # fast mode sits ON that line -- 0.90e-4 and 1.18e-4 from two builds of round 3 whose only arithmetic difference
-    # is the order in which a workgroup's waves add their SELayer partial sums (4 vs 8 waves) -- so it is asserted
-    # at 2e-4 there.  Stated, not hidden; DESIGN.md section 2 has the whole GOP-8 curve
-    fast = d.engine().precision != "fp32"
-    _check_sequence(d, i, fx, xs, 2, "seq_1088x1920", plane_bound=5e-3, deep_tol=5e-4, deep_total_tol=2e-4 if fast else TOL)
+    # mode).  Total bpp, mse and PSNR of the second P picture: within north_star's 1e-4 in BOTH modes (3e-6 exact,
+    # 9.1e-5 fast).  Round 3 asserted the fast mode at 2e-4 because two of its builds gave 0.90e-4 and 1.18e-4 -- their
+    # only arithmetic difference was the order in which a workgroup's waves added their SELayer partial sums; since
+    # round 4 that order belongs to the tile (test_k32_wave_count_changes_no_bit), the figure no longer depends on a
+    # tuning knob, and the bound is back at 1e-4.  DESIGN.md section 2 has the whole GOP-8 curve
+    _check_sequence(d, i, fx, xs, 2, "seq_1088x1920", plane_bound=5e-3, deep_tol=5e-4, deep_total_tol=TOL)
     d.engine().release()
     i.engine().release()
     torch.cuda.empty_cache()
@@ -252,14 +252,13 @@ def test_bench_size_gop8_curve_against_reference(nets):
     if out:
         with open(out, "a") as f:
             f.write("\n".join(lines) + "\n")
-    # What holds, and is asserted: the first P picture within north_star's 1e-4 on every total, the second within
-    # 1e-4 in the exact mode and 2e-4 in the fast mode (as in test_bench_size_matches_reference_fixture, which says why).  From the third picture on the rounding ties of the earlier pictures
+    # What holds, and is asserted: the first and the second P picture within north_star's 1e-4 on every total in both
+    # modes (test_bench_size_matches_reference_fixture says why the fast mode's second picture is back at 1e-4).  From the third picture on the rounding ties of the earlier pictures
     # have cascaded through the DPB and single pictures move by a few 1e-4 -- in the EXACT-fp32 mode as much as in the
     # split-fp16 mode (summation order against the CPU, not operand precision: DESIGN.md section 2) -- so deeper
     # pictures get a sanity bound, and the quantity a GOP-level comparison sees, the mean over the pictures, is bounded.
-    fast = d.engine().precision != "fp32"
     for t, dev in enumerate(curve, 1):
-        assert max(dev.values()) <= (TOL if t == 1 else (2e-4 if fast else TOL) if t == 2 else 1e-3), (t, dev)
+        assert max(dev.values()) <= (TOL if t <= 2 else 1e-3), (t, dev)
     d.engine().release()
     i.engine().release()
     torch.cuda.empty_cache()
