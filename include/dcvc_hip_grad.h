@@ -193,10 +193,11 @@ typedef struct {
 
 int dcvc_dual_prior_bwd(const dcvc_dual_prior_bwd_args *a, void *stream);
 
-/* g: (N) upstream gradient of the per-sample sums of dcvc_scale_bits (kind 0, Laplace);
+/* g: (N) upstream gradient of the per-sample sums of dcvc_scale_bits (kind 0: Laplace, get_y_laplace_bits,
+ * common_model.py:64-69; kind 1: Gaussian, get_y_gaussian_bits, :57-62 -- IntraNoAR's training mode, round 4);
  * dy, dscales: dense planes, written (=) */
 int dcvc_scale_bits_bwd(const float *y, const float *scales_hat, const float *g, float *dy, float *dscales,
-                        int32_t N, int64_t per_sample, void *stream);
+                        int32_t kind, int32_t N, int64_t per_sample, void *stream);
 /* dz (strided, +=) and dparams (11, C) += of dcvc_factorized_bits evaluated at z */
 int dcvc_factorized_bits_bwd(const float *z, int32_t z_cs, const float *params, const float *g, float *dz,
                              int32_t dz_cs, float *dparams, int32_t N, int32_t HW, int32_t C, void *stream);

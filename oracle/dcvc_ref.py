@@ -554,7 +554,7 @@ def intra_analysis(w, x, q_scale):
     q = lower_bound(w["q_basic"], 0.5) * q_scale
     y = encoder_stack(w, "enc", x) / q
     o["z"] = hyper_enc5(w, "hyper_enc", y)
-    o["z_hat"] = torch.round(o["z"])
+    o["z_hat"] = quant(o["z"])
     qs, sc, mu = three_convs(w, "y_prior_fusion", hyper_dec(w, "hyper_dec", o["z_hat"])).chunk(3, 1)
     o["y"] = dual_prior(w, "y_spatial_prior", y, mu, sc, qs)
     o["y_hat"] = o["y"]["y_hat"] * q
@@ -562,13 +562,18 @@ def intra_analysis(w, x, q_scale):
     return o
 
 
-def intra_forward(w, x, q_scale):
-    """IntraNoAR.forward in eval mode (image_model.py:54-106)."""
+def intra_forward(w, x, q_scale, noise=None):
+    """IntraNoAR.forward (image_model.py:54-106): eval mode, or -- inside training_mode() -- the training forward whose
+    add_noise draws (:79-80) are given as noise["y" | "z"]."""
     o = intra_analysis(w, x, q_scale)
     pix = x.size(2) * x.size(3)
     s = lambda t: torch.sum(t, dim=(1, 2, 3)) / pix
-    bpp_y = s(gaussian_bits(o["y"]["y_q"], o["y"]["scales_hat"]))
-    bpp_z = s(z_bits(w, "bit_estimator_z", o["z_hat"]))
+    if _TRAINING:
+        y_bit, z_bit = o["y"]["y_res"] + noise["y"], o["z"] + noise["z"]
+    else:
+        y_bit, z_bit = o["y"]["y_q"], o["z_hat"]
+    bpp_y = s(gaussian_bits(y_bit, o["y"]["scales_hat"]))
+    bpp_z = s(z_bits(w, "bit_estimator_z", z_bit))
     return {
         "x_hat": o["x_hat"],
         "mse": s((x - o["x_hat"]) ** 2),

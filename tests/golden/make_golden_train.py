@@ -124,7 +124,62 @@ def main(N=2, size=64, out_name="train_64", lambdas=None):
     np.savez_compressed(os.path.join(OUT, out_name + ".npz"), **fx)
 
 
+def main_intra(N=2, size=64, out_name="train_intra_64"):
+    """IntraNoAR in training mode (round 4): the reference's trainers run it under no_grad (core/model/dcvc_hem.py:164-167),
+    but image_model.py:54-106 is differentiable; loss = mean(bpp + LAMBDA * mse), one q-scale per sample.  Same contents as
+    the DMC fixtures: the two add_noise draws (y_res, z), scalars, per-parameter gradient norms and first values, dq."""
+    from vcm_ts_amd.params import intra_spec
+
+    _, IntraNoAR = load(with_cxx=False)
+    net = IntraNoAR()
+    net.load_state_dict(seeded_state_dict(intra_spec()))
+    net.train()
+    x = torch.from_numpy(frames(9, N, size, size))
+    q0 = torch.tensor([1.0, 0.8][:N]).view(N, 1, 1, 1)
+    draws, orig = [], net.add_noise
+
+    def add_noise(t):
+        out = orig(t)
+        draws.append((out - t).detach().clone())
+        return out
+
+    net.add_noise = add_noise
+    torch.manual_seed(200)
+    q = q0.clone().requires_grad_()
+    out = net(x, q)
+    loss = torch.mean(out["bpp"] + LAMBDA * out["mse"])
+    loss.backward()
+    fx = {"meta": np.array([N, size, LAMBDA], np.float64), "q": q0.reshape(-1).numpy().astype(np.float64),
+          "noise_y": draws[0].numpy().astype(np.float32), "noise_z": draws[1].numpy().astype(np.float32),
+          "loss": np.float64(loss.item()), "dq": q.grad.numpy().astype(np.float64), "bit": np.float64(out["bit"])}
+    for key in ("bpp", "bpp_y", "bpp_z", "mse"):
+        fx[key] = out[key].detach().numpy().astype(np.float64)
+    names, norms, heads = [], [], []
+    for name, prm in net.named_parameters():
+        names.append(name)
+        g = prm.grad
+        norms.append(-1.0 if g is None else g.double().norm().item())
+        h = np.zeros(8, np.float32)
+        if g is not None:
+            flat = g.reshape(-1)[:8].numpy()
+            h[:flat.size] = flat
+        heads.append(h)
+    fx["grad_names"], fx["grad_norm"], fx["grad_head"] = np.array(names), np.array(norms, np.float64), np.stack(heads)
+    named = list(net.named_parameters())
+    top = sorted(range(len(named)), key=lambda j: -norms[j])[:4]  # (192 x 192 x 9 filters: four in full are enough)
+    fx["grad_full_index"] = np.array(top, np.int64)
+    for j in top:
+        g = named[j][1].grad.double()
+        fx[f"grad_full_{j}"] = (g / g.norm()).reshape(-1).numpy().astype(np.float16)
+    np.savez_compressed(os.path.join(OUT, out_name + ".npz"), **fx)
+    print(f"{out_name}: loss {loss.item():.6f}, {sum(n >= 0 for n in norms)} parameter gradients")
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    main()
-    main(4, 256, "train_256_b4", (85.0, 170.0, 380.0, 840.0))
+    if len(sys.argv) > 1 and sys.argv[1] == "intra":
+        main_intra()
+    else:
+        main()
+        main(4, 256, "train_256_b4", (85.0, 170.0, 380.0, 840.0))
+        main_intra()

@@ -123,6 +123,72 @@ def test_frame_gradients_match_oracle_autograd(precision):
     assert G.frame_case(size=64, N=2, second=True, verbose=False, precision=precision) < 2e-3
 
 
+@pytest.mark.parametrize("precision", ["fp32", "fp16x3"])
+def test_intra_frame_gradients_match_reference_fixture(precision):
+    """IntraNoAR in .train() mode (round 4; image_model.py:54-106 is differentiable although the reference's trainers
+    run it under no_grad): loss, rate / distortion and every parameter's gradient against the numbers the REFERENCE
+    produced with torch.autograd (tests/golden/train_intra_64.npz: Gaussian likelihood of the noisy residual,
+    straight-through round, UNet + SE synthesis), in both arithmetic modes; then the optimiser can step on it."""
+    from tests.util import golden
+    from vcm_ts_amd.intra import IntraNoAR
+    from vcm_ts_amd.synthetic import frames
+
+    fx = golden("train_intra_64")
+    N, size, lam = int(fx["meta"][0]), int(fx["meta"][1]), float(fx["meta"][2])
+    dev = torch.device("cuda:0")
+    m = IntraNoAR(precision=precision).to(dev).train()
+    for p in m.parameters():
+        p.requires_grad_(True)
+    x = torch.from_numpy(frames(9, N, size, size)).to(dev)
+    q = torch.from_numpy(fx["q"]).float().to(dev).view(N, 1, 1, 1).requires_grad_()
+    m._noise_override = {"y": torch.from_numpy(fx["noise_y"]), "z": torch.from_numpy(fx["noise_z"])}
+    out = m(x, q)
+    loss = torch.mean(out["bpp"] + lam * out["mse"])
+    loss.backward()
+    m._noise_override = None
+    for key in ("bpp", "bpp_y", "bpp_z", "mse"):
+        np.testing.assert_allclose(out[key].detach().cpu().numpy(), fx[key], rtol=1e-4, err_msg=key)
+    assert abs(loss.item() - float(fx["loss"])) <= 1e-4 * abs(float(fx["loss"]))
+    assert abs(out["bit"] - float(fx["bit"])) <= 1e-4 * float(fx["bit"]) and isinstance(out["bit"], float)
+    got_q, want_q = q.grad.cpu().numpy().reshape(-1).astype(np.float64), fx["dq"].reshape(-1)
+    assert np.linalg.norm(got_q - want_q) <= 5e-2 * np.linalg.norm(want_q), (got_q, want_q)
+    params = dict(m.named_parameters())
+    names = [str(n) for n in fx["grad_names"]]
+    total = float(np.sqrt(sum(float(v) ** 2 for v in fx["grad_norm"] if v > 0)))
+    sq_ref = sq_diff = 0.0
+    worst = ("", 0.0)
+    for i, name in enumerate(names):
+        want = float(fx["grad_norm"][i])
+        g = params[name].grad
+        if want <= 0:
+            assert g is None or float(g.norm()) == 0.0, name
+            continue
+        assert g is not None, name
+        got = float(g.double().norm())
+        tol_t = 2e-2 if want < 1e-2 * total else 5e-3
+        assert abs(got - want) <= tol_t * want + 1e-8, (name, got, want)
+        head = g.reshape(-1)[:8].cpu().numpy()
+        np.testing.assert_allclose(head, fx["grad_head"][i][: head.size], rtol=0, atol=2 * tol_t * want + 1e-8, err_msg=name)
+        sq_ref += want * want
+        sq_diff += (got - want) ** 2
+        if abs(got - want) / want > worst[1]:
+            worst = (name, abs(got - want) / want)
+    print(f"\n[train_intra_64 {precision}] gradient norms vs the reference: whole {sq_diff ** 0.5 / sq_ref ** 0.5:.2e}, worst tensor {worst[0]} {worst[1]:.2e}")
+    assert sq_diff ** 0.5 <= 2e-3 * sq_ref ** 0.5
+    for j in fx["grad_full_index"]:
+        u = fx[f"grad_full_{int(j)}"].astype(np.float64)
+        g = params[names[int(j)]].grad.double().reshape(-1).cpu().numpy()
+        assert float(g @ u / (np.linalg.norm(g) * np.linalg.norm(u))) >= 0.9999, names[int(j)]
+    # and a second forward / backward after an optimiser step runs on the re-packed filters
+    opt = torch.optim.SGD(m.parameters(), lr=1e-6)
+    opt.step()
+    opt.zero_grad()
+    out2 = m(x, q.detach())
+    torch.mean(out2["bpp"] + lam * out2["mse"]).backward()
+    assert all(torch.isfinite(p.grad).all() for p in m.parameters() if p.grad is not None)
+    assert float(out2["mse"].sum()) != float(out["mse"].sum())
+
+
 def test_reverse_pass_enqueues_no_aten_arithmetic_beside_the_weight_gradient_stream():
     """the library is built without packed-FP32 instructions because one of its kernels once computed
     differently while 16-bit-MFMA kernels shared the SIMDs; ATen's arithmetic kernels are not built that

@@ -567,12 +567,16 @@ def test_requires_update_and_padding(nets):
         fresh.compress(x, dpb, 1.0, 1.0)
     with pytest.raises(AssertionError):
         fresh.forward_one_frame(torch.rand(1, 3, 60, 64).cuda(), dpb, 1.0, 1.0)
-    # the I-picture codec has no training path (the reference trains only DMC and runs IntraNoAR
-    # under no_grad, core/model/dcvc_hem.py:164-167): refuse loudly instead of returning eval numbers
+    # the I-picture codec's training mode (round 4; tests/test_gpu_backward.py has its gradients): noisy-latent bit
+    # estimate, same distortion, `bit` a float as in the reference (image_model.py:102)
     from vcm_ts_amd.intra import IntraNoAR
 
-    with pytest.raises(RuntimeError):
-        IntraNoAR().cuda().train()(x, 1.0)
+    inet = IntraNoAR().cuda()
+    ti = inet.train()(x, 1.0)
+    ei = inet.eval()(x, 1.0)
+    assert isinstance(ti["bit"], float) and ti["bpp"].shape == (1,) and torch.isfinite(ti["bpp"]).all()
+    torch.testing.assert_close(ti["mse"], ei["mse"], rtol=1e-5, atol=0)
+    assert float((ti["bpp"] - ei["bpp"]).abs()) > 0
     # training-mode DMC forward: noisy-latent bit estimate differs from the eval estimate, same distortion
     ev = fresh(x, dpb, 1.0, 1.0)
     tr = fresh.train()(x, dpb, 1.0, 1.0)

@@ -65,3 +65,40 @@ def test_training_forward_and_gradients_match_reference(name):
             want_u = fx[p + f"grad_full_{int(j)}"].astype(np.float64)
             g = w[names[int(j)]].grad.double().reshape(-1).numpy()
             assert g @ want_u / (np.linalg.norm(g) * np.linalg.norm(want_u)) >= 0.999999, names[int(j)]
+
+
+def test_intra_training_forward_and_gradients_match_reference():
+    """IntraNoAR's training-mode forward (image_model.py:54-106 with self.training: Gaussian likelihood of the noisy
+    residual, straight-through round) through the oracle against tests/golden/train_intra_64.npz, produced by running the
+    reference's IntraNoAR in .train() mode and torch.autograd (make_golden_train.py intra)."""
+    from vcm_ts_amd.params import intra_spec
+
+    fx = golden("train_intra_64")
+    N, size, lam = int(fx["meta"][0]), int(fx["meta"][1]), float(fx["meta"][2])
+    w = {k: v.clone().requires_grad_() for k, v in seeded_state_dict(intra_spec()).items()}
+    x = torch.from_numpy(frames(9, N, size, size))
+    q = torch.from_numpy(fx["q"]).float().view(N, 1, 1, 1).requires_grad_()
+    noise = {"y": torch.from_numpy(fx["noise_y"]), "z": torch.from_numpy(fx["noise_z"])}
+    with R.training_mode():
+        out = R.intra_forward(w, x, q, noise=noise)
+    loss = torch.mean(out["bpp"] + lam * out["mse"])
+    loss.backward()
+    for key in ("bpp", "bpp_y", "bpp_z", "mse"):
+        np.testing.assert_allclose(out[key].detach().numpy(), fx[key], rtol=3e-5, err_msg=key)
+    assert abs(loss.item() - float(fx["loss"])) <= 3e-5 * abs(float(fx["loss"]))
+    np.testing.assert_allclose(q.grad.numpy(), fx["dq"], rtol=1e-4, atol=1e-7)
+    for i, name in enumerate(str(n) for n in fx["grad_names"]):
+        want = float(fx["grad_norm"][i])
+        g = w[name].grad
+        if want <= 0:
+            assert g is None or float(g.norm()) == 0.0, name
+            continue
+        got = float(g.double().norm())
+        assert abs(got - want) <= 1e-4 * want + 1e-9, (name, got, want)
+        head = g.reshape(-1)[:8].numpy()
+        np.testing.assert_allclose(head, fx["grad_head"][i][: head.size], rtol=0, atol=1e-4 * want + 1e-9, err_msg=name)
+    for j in fx["grad_full_index"]:
+        name = str(fx["grad_names"][int(j)])
+        u = fx[f"grad_full_{int(j)}"].astype(np.float64)
+        g = w[name].grad.double().reshape(-1).numpy()
+        assert float(g @ u / (np.linalg.norm(g) * np.linalg.norm(u))) >= 0.999999, name

@@ -984,11 +984,31 @@ __global__ void dual_prior_bwd_kernel(const dcvc_dual_prior_bwd_args a, int64_t 
 __device__ __forceinline__ float sgn(float v) { return (float)((v > 0.f) - (v < 0.f)); }
 
 __global__ void scale_bits_bwd_kernel(const float *__restrict__ yv, const float *__restrict__ sh, const float *__restrict__ g,
-                                      float *__restrict__ dy, float *__restrict__ dsc, int64_t per, int64_t total) {
+                                      float *__restrict__ dy, float *__restrict__ dsc, int kind, int64_t per, int64_t total) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
     const float up = g[i / per];
     const float y = yv[i], s_raw = sh[i];
+    if (kind == 1) {
+        // get_y_gaussian_bits (common_model.py:57-62; IntraNoAR): sigma.clamp(0.11, 1e10), Normal(0, sigma).cdf(v) =
+        // 0.5 * (1 + erf(v * (1 / sigma) / sqrt(2))) as torch.distributions writes it; autograd: erf'(u) = 2/sqrt(pi) exp(-u^2),
+        // (1 / sigma)' = -1 / sigma^2, clamp passes the gradient inside its range
+        const float sg = fminf(fmaxf(s_raw, 0.11f), 1e10f);
+        const float rs = 1.f / sg;
+        const float t1 = y + 0.5f, t0 = y - 0.5f;
+        const float u1 = t1 * rs / 1.4142135623730951f, u0 = t0 * rs / 1.4142135623730951f;
+        const float p = 0.5f * (1.f + erff(u1)) - 0.5f * (1.f + erff(u0));
+        const float bits = (-1.0f * logf(p + 1e-5f)) / 0.6931471805599453f;
+        const float gb = (bits >= 0.f || up < 0.f) ? up : 0.f;
+        const float gp = -gb / ((p + 1e-5f) * 0.6931471805599453f);
+        const float c = 0.5f * 1.1283791670955126f;  // 0.5 * 2 / sqrt(pi)
+        const float d1 = c * expf(-u1 * u1), d0 = c * expf(-u0 * u0);  // d cdf / d u
+        dy[i] = gp * (d1 - d0) * rs / 1.4142135623730951f;
+        const float du_ds1 = -t1 * rs * rs / 1.4142135623730951f, du_ds0 = -t0 * rs * rs / 1.4142135623730951f;
+        const bool in_range = s_raw >= 0.11f && s_raw <= 1e10f;
+        dsc[i] = in_range ? gp * (d1 * du_ds1 - d0 * du_ds0) : 0.f;
+        return;
+    }
     const float b = fminf(fmaxf(s_raw, 1e-5f), 1e10f);
     const float t1 = y + 0.5f, t0 = y - 0.5f;
     const float s1 = sgn(t1), s0 = sgn(t0);
@@ -1417,11 +1437,11 @@ extern "C" int dcvc_dual_prior_bwd(const dcvc_dual_prior_bwd_args *a, void *stre
 }
 
 extern "C" int dcvc_scale_bits_bwd(const float *y, const float *scales_hat, const float *g, float *dy, float *dscales,
-                                   int32_t N, int64_t per_sample, void *stream) {
-    if (!y || !scales_hat || !g || !dy || !dscales || N <= 0 || per_sample <= 0) return DCVC_E_ARG;
+                                   int32_t kind, int32_t N, int64_t per_sample, void *stream) {
+    if (!y || !scales_hat || !g || !dy || !dscales || N <= 0 || per_sample <= 0 || (kind != 0 && kind != 1)) return DCVC_E_ARG;
     const int64_t total = (int64_t)N * per_sample;
     hipLaunchKernelGGL(scale_bits_bwd_kernel, dim3(nblk(total, 256)), dim3(256), 0, (hipStream_t)stream, y, scales_hat, g,
-                       dy, dscales, per_sample, total);
+                       dy, dscales, kind, per_sample, total);
     RET_LAUNCH();
 }
 

@@ -142,14 +142,6 @@ class CodecBase(nn.Module):
         self._net = None
         return self
 
-    def _eval_only(self):
-        """IntraNoAR only: the reference never trains the I-picture codec on this path (it runs under
-        no_grad, core/model/dcvc_hem.py:164-167), so a training-mode forward (noisy latents,
-        straight-through round, common_model.py:38-49) is refused rather than silently returning
-        eval numbers.  DMC has a training path (DMC._forward_train)."""
-        if self.training:
-            raise RuntimeError("IntraNoAR has no training-mode forward on the HIP path: call .eval() first")
-
     def _qvec(self, q, N, default_param=None):
         """q-scale argument (None | float | 0-d / (N,1,1,1) tensor) -> (N,) fp32 device tensor."""
         if q is None:

@@ -385,13 +385,13 @@ class Tape:
             self.channel_dot(plane, None, self.q[qkey]["dq_mul"], over_batch=False, accumulate=True)
 
     # -- rate / distortion ---------------------------------------------------------------------
-    def _b_scale_bits(self, name, y_bit, scales_hat, y_res, N, per):
+    def _b_scale_bits(self, name, y_bit, scales_hat, y_res, N, per, kind=0):
         g = self.up.get(name)
         if g is None:
             return
         dy, dsc = torch.empty_like(y_bit), torch.empty_like(scales_hat)
         lib.check(self.L.dcvc_scale_bits_bwd(y_bit.data_ptr(), scales_hat.data_ptr(), g.data_ptr(), dy.data_ptr(),
-                                             dsc.data_ptr(), N, per, self.stream()), "scale_bits_bwd")
+                                             dsc.data_ptr(), kind, N, per, self.stream()), "scale_bits_bwd")
         self.dense[y_res.data_ptr()] = dy
         self.dense[scales_hat.data_ptr()] = dsc
 

@@ -14,9 +14,53 @@ import time
 import torch
 
 from . import entropy as E
+from . import lib
 from . import stream as S
 from .dmc import CodecBase
+from .engine import View
 from .params import intra_spec
+
+
+class _IntraFn(torch.autograd.Function):
+    """One I picture in training mode as a single autograd node (the counterpart of dmc._FrameFn): forward records a
+    grad.Tape on the HIP engine, backward replays it with the kernels of include/dcvc_hip_grad.h.  Inputs after the
+    q-scale are the model's parameters; outputs are the per-sample sums (bits_y, bits_z, squared error) and x_hat."""
+
+    @staticmethod
+    def forward(ctx, model, x, q, *params):
+        from .grad import Tape
+
+        ctx.set_materialize_grads(False)
+        tape = Tape(model.engine())
+        o, sums = model._train_frame(tape, x.detach(), q.detach())
+        ctx.tape, ctx.params, ctx.q_shape, ctx.out_view = tape, params, q.shape, o["x_hat"]
+        return sums["bits_y"], sums["bits_z"], sums["sq"], o["x_hat"].nchw()
+
+    @staticmethod
+    def backward(ctx, g_y, g_z, g_sq, g_xhat):
+        tape = ctx.tape
+        if tape is None:
+            raise RuntimeError("this picture's tape was already consumed (retain_graph is not supported)")
+        e = tape.e
+        for name, g in (("bits_y", g_y), ("bits_z", g_z), ("sq", g_sq)):
+            if g is not None:
+                tape.up[name] = g.detach().to(torch.float32).contiguous()
+        if g_xhat is not None:  # a loss computed on the reconstruction by the caller (perceptual terms)
+            e.from_nchw(g_xhat, tape.grad(ctx.out_view))
+        tape.backward()
+        grads = []
+        for p, need in zip(ctx.params, ctx.needs_input_grad[3:]):
+            g = tape.pgrads.get(id(p)) if need else None
+            grads.append(torch.zeros_like(p) if (need and g is None) else g)
+        gq = None
+        if ctx.needs_input_grad[2]:
+            g = tape.q["y"]["dq_scale"]
+            n = 1
+            for s_ in ctx.q_shape:
+                n *= s_
+            gq = (g.sum() if n == 1 else g.clone()).reshape(ctx.q_shape)
+        ctx.tape = None
+        return (None, None, gq, *grads)
 
 
 class IntraNoAR(CodecBase):
@@ -36,7 +80,7 @@ class IntraNoAR(CodecBase):
     def _synthesis(self, net, y_hat, N, H, W, clamp):
         d = net.decoder_stack("dec", y_hat)
         u = net.unet("refine.0", d)
-        k = self._out_set()
+        k = self._out_set() if self.engine().tape is None else 0  # (a recorded forward owns fresh buffers)
         x_hat = net.buf(f"dpb{k}.x_hat", N=N, H=H, W=W, C=3)
         net.conv("refine.1", u, out=x_hat, out_slope="clamp01" if clamp else None)
         return x_hat
@@ -45,7 +89,8 @@ class IntraNoAR(CodecBase):
         """image_model.py:50-52: max(q_basic, 0.5) * q_scale."""
         return torch.clamp_min(self.P("q_basic"), 0.5) * q_scale
 
-    def _run(self, x, q_scale, mode):
+    def _run(self, x, q_scale, mode, tape=None):
+        """mode 'estimate' / 'compress' / 'train' (a recorded forward: straight-through rounding, y_res kept)."""
         e = self.engine()
         net = self._net
         Nb, _, H, W = x.shape
@@ -53,8 +98,10 @@ class IntraNoAR(CodecBase):
         q = self._qvec(q_scale, Nb, "q_scale")
         qb = self.P("q_basic").reshape(-1)
         x3 = self._frame_in("x", x)
+        if tape is not None:
+            tape.mark_const(x3)  # the picture carries no gradient
         y_raw = net.encoder_stack("enc", x3)
-        y = e.scale_channels(y_raw, net.buf("y", like=y_raw, C=self.N), qb, q)
+        y = e.scale_channels(y_raw, net.buf("y", like=y_raw, C=self.N), qb, q, qkey="y")
         z = net.hyper_enc5("hyper_enc", y)
         z_hat = net.buf("z_hat", like=z, C=self.N)
         sym_z = e.ibuf("intra/sym_z", Nb * self.N * z.HW) if mode == "compress" else None
@@ -62,14 +109,77 @@ class IntraNoAR(CodecBase):
         e.round_symbols(z, z_hat, sym_z)
         fusion = net.three_convs("y_prior_fusion", net.hyper_dec("hyper_dec", z_hat))
         y_hat = net.buf("y_hat", like=y, C=self.N)
-        r = self._dual_prior_encode("y", y, fusion, "y_spatial_prior", y_hat, qb, q, want_stats=(mode == "estimate"),
-                                    want_symbols=(mode == "compress"))
+        r = self._dual_prior_encode("y", y, fusion, "y_spatial_prior", y_hat, qb, q, want_stats=(mode != "compress"),
+                                    want_symbols=(mode == "compress"), want_res=(mode == "train"), qkey="y")
         x_hat = self._synthesis(net, y_hat, Nb, H, W, clamp=(mode == "compress"))  # compress == decoder output
-        return dict(N=Nb, H=H, W=W, x3=x3, y=y, z_hat=z_hat, sym_z=sym_z, r=r, x_hat=x_hat, y_hat=y_hat)
+        return dict(N=Nb, H=H, W=W, x3=x3, y=y, z=z, z_hat=z_hat, sym_z=sym_z, r=r, x_hat=x_hat, y_hat=y_hat)
 
-    @torch.no_grad()
+    # ------------------------------------------------------------------ training-mode forward (round 4)
+    _noise_override = None  # tests: {"y", "z"} -> NCHW tensors replacing add_noise's draws
+
+    def _noise(self, key, N, H, W, C_):
+        """uniform(-0.5, 0.5) like CompressionModel.add_noise (common_model.py:46-49), dense NHWC."""
+        if self._noise_override is not None:
+            t = self._noise_override[key].to(device=self.device, dtype=torch.float32)
+            assert tuple(t.shape) == (N, C_, H, W), (key, t.shape)
+            return t.permute(0, 2, 3, 1).contiguous()
+        return torch.empty((N, H, W, C_), dtype=torch.float32, device=self.device).uniform_(-0.5, 0.5)
+
+    def _train_frame(self, tape, x, q_scale):
+        """Recorded forward of IntraNoAR.forward in training mode (image_model.py:54-100 with self.training: straight-through
+        rounding, uniform noise on the residual and on z for the bit estimates, Gaussian likelihood).  The reference's
+        trainers run the I-picture codec under no_grad (core/model/dcvc_hem.py:164-167), but its forward IS
+        differentiable; this is that path.  Returns the views and the per-sample sums."""
+        e = self.engine()
+        e.tape = tape
+        try:
+            e.repack_all()
+            N = x.shape[0]
+            tape.qstate("y", self.P("q_basic"), self._qvec(q_scale, N, "q_scale"), N, self.N)
+            o = self._run(x, tape.q["y"]["q_scale"], "train", tape=tape)
+            L, sums = e.L, {}
+            sums["sq"] = e.sq_err(o["x_hat"], o["x3"])
+            tape.ops.append(("sq_err", "sq", o["x_hat"], o["x3"]))
+            lat, r = o["y"], o["r"]
+            per = lat.HW * lat.C
+            noise = self._noise("y", N, lat.H, lat.W, lat.C)
+            y_bit = torch.empty_like(noise).view(-1)
+            lib.check(L.dcvc_add_planes(r["y_res"].data_ptr(), lat.C, noise.data_ptr(), lat.C, y_bit.data_ptr(), lat.C,
+                                        N * lat.HW, lat.C, e.stream()), "add_planes")
+            sums["bits_y"] = e.scale_bits(y_bit, r["scales_hat"], N, per, gaussian=True)
+            tape.ops.append(("scale_bits", "bits_y", y_bit, r["scales_hat"], r["y_res"], N, per, 1))
+            z = o["z"]
+            noise = self._noise("z", N, z.H, z.W, z.C)
+            z_bit = View(torch.empty_like(noise), z.C)
+            lib.check(L.dcvc_add_planes(z.ptr, z.cs, noise.data_ptr(), z.C, z_bit.ptr, z_bit.cs, N * z.HW, z.C, e.stream()),
+                      "add_planes")
+            blk = self._zblock("bit_estimator_z")
+            sums["bits_z"] = e.factorized_bits(z_bit, blk)
+            plist = [self.P(f"bit_estimator_z.f{i}.{k}") for i in (1, 2, 3) for k in ("h", "b", "a")]
+            plist += [self.P("bit_estimator_z.f4.h"), self.P("bit_estimator_z.f4.b")]
+            tape.ops.append(("factorized_bits", "bits_z", z_bit, z, blk, plist))
+            return o, sums
+        finally:
+            e.tape = None
+
+    def _forward_train(self, x, q_scale):
+        q = self.P("q_scale") if q_scale is None else q_scale
+        q = q if torch.is_tensor(q) else torch.tensor(float(q), device=self.device)
+        params = [p for n, p in self._pmap.items() if n != "q_scale"]
+        bits_y, bits_z, sq, x_hat = _IntraFn.apply(self, x, q, *params)
+        pix = x.shape[2] * x.shape[3]
+        bpp_y, bpp_z = bits_y / pix, bits_z / pix
+        return {"x_hat": x_hat, "mse": sq / pix, "bit": (torch.sum(bpp_y + bpp_z) * pix).item(), "bpp": bpp_y + bpp_z,
+                "bpp_y": bpp_y, "bpp_z": bpp_z}
+
     def forward(self, x, q_scale=None):
-        self._eval_only()
+        """Training mode (round 4): the differentiable forward of image_model.py:54-106 (`bit` stays a float, :102)."""
+        if self.training:
+            return self._forward_train(x, q_scale)
+        with torch.no_grad():
+            return self._forward_eval(x, q_scale)
+
+    def _forward_eval(self, x, q_scale=None):
         e = self.engine()
         o = self._run(x, q_scale, "estimate")
         pix = o["H"] * o["W"]

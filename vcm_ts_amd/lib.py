@@ -182,7 +182,7 @@ _SIGS = {
     "dcvc_scale_channels_bwd": [vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, vp],
     "dcvc_q_finish": [vp, vp, vp, vp, vp, vp, i32, i32, vp],
     "dcvc_dual_prior_bwd": [C.POINTER(DualPriorBwdArgs), vp],
-    "dcvc_scale_bits_bwd": [vp, vp, vp, vp, vp, i32, i64, vp],
+    "dcvc_scale_bits_bwd": [vp, vp, vp, vp, vp, i32, i32, i64, vp],
     "dcvc_factorized_bits_bwd": [vp, i32, vp, vp, vp, i32, vp, i32, i32, i32, vp],
     "dcvc_sq_err_bwd": [vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, vp],
     # include/dcvc_hip_rans.h
