@@ -259,6 +259,8 @@ def test_bench_size_gop8_curve_against_reference(nets):
     # pictures get a sanity bound, and the quantity a GOP-level comparison sees, the mean over the pictures, is bounded.
     for t, dev in enumerate(curve, 1):
         assert max(dev.values()) <= (TOL if t <= 2 else 1e-3), (t, dev)
+    # what a GOP-level comparison sees: the mean over the pictures (2.6e-4 fast / 1.7e-4 exact measured in round 4)
+    assert float(np.mean([max(dev.values()) for dev in curve])) <= 4e-4, curve
     d.engine().release()
     i.engine().release()
     torch.cuda.empty_cache()
