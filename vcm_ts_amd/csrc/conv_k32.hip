@@ -481,6 +481,7 @@ extern "C" int dcvc_conv2d_k32(const dcvc_conv_args *a, void *stream) {
     if (!a || a->nseg < 1 || a->nseg > DCVC_MAX_SEG || !a->out || !a->wpack || !a->bpack) return DCVC_E_ARG;
     if (a->stride != 1 || (a->ks != 1 && a->ks != 3) || a->precision != DCVC_PREC_FP16X3) return DCVC_E_ARG;
     if (a->Cout_pad % 32 || a->Cout > a->Cout_pad || (a->pixel_shuffle && (a->Cout & 3))) return DCVC_E_ARG;
+    if (a->out_act < 0 || a->out_act > 2) return DCVC_E_ARG;  // (the mask epilogue, out_act 3, is dcvc_conv2d's)
     K32 k;
     memset(&k, 0, sizeof(k));
     for (int s = 0; s < a->nseg; ++s) {

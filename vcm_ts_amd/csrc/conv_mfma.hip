@@ -371,7 +371,14 @@ __global__ __launch_bounds__(256, 2) void conv_mfma(const ConvK a) {
                         v = v + rv[m][it];
                     }
                 }
-                if (a.res2) v = rv2[m][it] + v;
+                if (a.res2) {
+                    if (a.out_act == 3) {  // res2 is a MASK SOURCE: v *= LeakyReLU'(res2) (dcvc_hip.h, out_act 3)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] *= rv2[m][it][e] > 0.f ? 1.f : a.out_slope;
+                    } else {
+                        v = rv2[m][it] + v;
+                    }
+                }
                 if (a.chan_partial && ok[m][it]) csum += v;
                 if (a.status && ok[m][it])
                     vmax = fmaxf(vmax, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
@@ -437,7 +444,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma(const ConvK a) {
                 const size_t pix = a.ps ? ((size_t)(img * Ho + 2 * oy + dy) * Wo + 2 * ox + dx)
                                         : ((size_t)(img * Ho + oy) * Wo + ox);
                 if (a.res) v = a.res_gate ? __builtin_fmaf(rv[r], gate, v) : v + rv[r];
-                if (a.res2) v = rv2[r] + v;
+                if (a.res2) v = a.out_act == 3 ? v * (rv2[r] > 0.f ? 1.f : a.out_slope) : rv2[r] + v;
                 if (a.status) vmax = fmaxf(vmax, fabsf(v));
                 a.out[pix * a.out_cs + cf] = v;
             }

@@ -272,6 +272,7 @@ extern "C" int dcvc_conv_small_pack_weights(const float *w, const float *b, int3
 // dcvc_conv_args as for dcvc_conv2d, restricted to: Cout <= 16, ks 3 or 7, stride 1, no pixel shuffle, no gate,
 // no second residual, no chan_partial; wpack / bpack from dcvc_conv_small_pack_weights; DCVC_PREC_FP16X3.
 extern "C" int dcvc_conv2d_small(const dcvc_conv_args *a, void *stream) {
+    if (a && (a->out_act < 0 || a->out_act > 2)) return DCVC_E_ARG;  // (the mask epilogue, out_act 3, is dcvc_conv2d's)
     if (!a || a->nseg < 1 || a->nseg > DCVC_MAX_SEG || !a->out || !a->wpack || !a->bpack) return DCVC_E_ARG;
     if (a->tile_rows > 0) return DCVC_E_ARG;  // no banded launches for this kernel
     if (a->Cout <= 0 || a->Cout > 16 || (a->ks != 3 && a->ks != 7) || a->stride != 1 || a->pixel_shuffle || a->res_gate ||

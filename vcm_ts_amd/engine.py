@@ -533,7 +533,7 @@ class Engine:
         a.nseg, a.N, a.Hin, a.Win = len(srcs), s0.N, s0.H, s0.W
         a.in_act, a.in_slope = (0, 0.0) if in_slope is None else (1, in_slope)
         small = band is None and self.small_capable(pk, stride, gate, res2, chan_partial)
-        k32 = not small and self.k32_capable(pk, stride, out, res, res2, gate, srcs)
+        k32 = not small and not isinstance(out_slope, tuple) and self.k32_capable(pk, stride, out, res, res2, gate, srcs)
         paired = not small and not k32 and self.pair_capable(pk, stride)
         wq = self.pack_small(pk) if small else (self.pack_k32(pk) if k32 else (self.pack_paired(pk) if paired else pk))
         a.pair_taps = int(paired)
@@ -546,7 +546,11 @@ class Engine:
         cfin = pk.Cout // 4 if pk.ps else pk.Cout
         assert (out.N, out.H, out.W, out.C) == (s0.N, Ho * m, Wo * m, cfin), (out, Ho, Wo, cfin)
         a.out, a.out_cs = out.ptr, out.cs
-        a.out_act, a.out_slope = (0, 0.0) if out_slope is None else ((2, 0.0) if out_slope == "clamp01" else (1, out_slope))
+        if isinstance(out_slope, tuple):  # ("mask", slope): res2 is the mask source (dcvc_conv_args.out_act 3)
+            assert out_slope[0] == "mask" and res2 is not None and not (small or k32)
+            a.out_act, a.out_slope = 3, float(out_slope[1])
+        else:
+            a.out_act, a.out_slope = (0, 0.0) if out_slope is None else ((2, 0.0) if out_slope == "clamp01" else (1, out_slope))
         a.pixel_shuffle = int(pk.ps)
         a.precision = pk.precision
         if res is not None:

@@ -42,6 +42,9 @@ class Tape:
         self.pool = []        # zero-filled chunks the gradient buffers are carved from (one memset each)
         self.pool_left = 0
         self.parena = None    # (flat zero-filled tensor, {id(parameter): offset}) when parameter gradients share one buffer
+        self.fused_dpre = {}  # forward base data_ptr of a convolution output -> its pre-activation gradient, already
+                              # computed by the data-gradient launch of its only consumer (round 4, _plan_fusion)
+        self.fuse = {}        # forward base data_ptr -> the producing conv op, for outputs eligible for that fusion
 
     # ------------------------------------------------------------------ bookkeeping
     def mark_const(self, v: View):
@@ -126,6 +129,7 @@ class Tape:
         saved, e.tape = e.tape, None  # the gradient launches themselves are not recorded
         guard, e.guard_outputs = e.guard_outputs, False  # the data-gradient launches reuse the forward kernel on gradients
         try:
+            self._plan_fusion()
             for op in reversed(self.ops):
                 getattr(self, "_b_" + op[0])(*op[1:])
             for qk, q in self.q.items():
@@ -137,10 +141,60 @@ class Tape:
             e.guard_outputs = guard
 
     # -- convolution ----------------------------------------------------------------------
+    epilogue_fusion = True  # (developer A/B: False keeps one epilogue-backward launch per activated convolution)
+
+    def _plan_fusion(self):
+        """Which convolution outputs get their epilogue backward from their consumer (round 4).  A layer whose epilogue is
+        a LeakyReLU / ReLU only and whose output feeds exactly ONE later convolution (whole tensor, no activation on load)
+        needs dpre = dout * act'(out), and dout is produced by nothing but that consumer's data-gradient launch: the
+        launch applies the mask in its epilogue (dcvc_conv_args.out_act 3, mask source = the forward activation) and
+        writes dpre directly -- no zero-filled gradient buffer, no accumulate read, no epilogue-backward launch.  The
+        values are the same bit for bit (0 + v, then v * m).  Eligibility is decided by counting every appearance of a
+        forward buffer among the recorded operations' arguments: producer + one consumer = 2."""
+        self.fuse, self.fused_dpre = {}, {}
+        if not self.epilogue_fusion:
+            return
+        uses, producer = {}, {}
+
+        def walk(a):
+            if isinstance(a, View):
+                k = a.base.data_ptr()
+                uses[k] = uses.get(k, 0) + 1
+            elif isinstance(a, (tuple, list)):
+                for x in a:
+                    walk(x)
+            elif isinstance(a, dict):
+                for x in a.values():
+                    walk(x)
+
+        for op in self.ops:
+            walk(op[1:])
+            if op[0] == "conv":
+                pk, srcs, out, stride, in_slope, out_slope, res, gate, res2 = op[1:]
+                if (out_slope is not None and out_slope != "clamp01" and res is None and res2 is None and gate is None
+                        and not pk.ps and stride == 1):
+                    producer[out.base.data_ptr()] = op
+        for k, op in producer.items():
+            if uses.get(k) == 2 and k not in self.gbufs:
+                self.fuse[k] = op
+
+    def _fusable(self, s: View, in_slope):
+        """The producing conv op if this source view's gradient can be written as the producer's dpre, else None."""
+        if in_slope is not None or self.is_const(s):
+            return None
+        op = self.fuse.get(s.base.data_ptr())
+        if op is None:
+            return None
+        out = op[3]
+        if (out.ptr, out.C, out.cs, out.N, out.H, out.W) != (s.ptr, s.C, s.cs, s.N, s.H, s.W):
+            return None
+        return op
+
     def _b_conv(self, pk, srcs, out, stride, in_slope, out_slope, res, gate, res2):
         e, L = self.e, self.L
-        dout = self.grad(out, create=False)
-        if dout is None:
+        fused = self.fused_dpre.pop(out.base.data_ptr(), None)
+        dout = None if fused is not None else self.grad(out, create=False)
+        if dout is None and fused is None:
             return
         s0 = srcs[0]
         ks = pk.ks
@@ -150,7 +204,10 @@ class Tape:
         act = out_slope is not None
         assert out_slope != "clamp01", "clamped outputs are not differentiable (compress mode only)"
         need_pro = act or res is not None or res2 is not None or pk.ps or stride == 2
-        if need_pro:
+        if fused is not None:  # the consumer's data-gradient launch already wrote dpre (see _plan_fusion)
+            zs, Hd, Wd = 1, Ho, Wo
+            dpre, need_pro = fused, False
+        elif need_pro:
             zs = stride
             Hd, Wd = (s0.H, s0.W) if zs == 2 else (Ho, Wo)
             t = (torch.zeros if zs == 2 else torch.empty)((N, Hd, Wd, _r4(Cout)), dtype=torch.float32, device=e.device)
@@ -203,7 +260,7 @@ class Tape:
             ready = torch.cuda.Event()
             ready.record(main)
             side.wait_event(ready)
-            if need_pro:
+            if need_pro or fused is not None:
                 if torch.cuda.is_current_stream_capturing():
                     self.keep.append(dpre.base)  # (a captured pass keeps its temporaries: the graph owns them anyway)
                 else:
@@ -230,6 +287,15 @@ class Tape:
         for s in srcs:
             if not self.is_const(s):
                 pkT = e.pack_dev((pk.key, "T", o), pk.weight, None, (s.C,), False, cin_slice=(o, o + s.C), transposed=True)
+                prod = self._fusable(s, in_slope)
+                if prod is not None and s.base.data_ptr() not in self.gbufs:
+                    # s is the activated output of `prod` and this launch is its only gradient source: write the
+                    # producer's dpre = conv * act'(s) directly (mask source: the forward activation itself)
+                    dp = View(torch.empty((s.N, s.H, s.W, _r4(s.C)), dtype=torch.float32, device=e.device), s.C)
+                    e.conv(pkT, [dsrc_in], dp, out_slope=("mask", float(prod[6])), res2=s)
+                    self.fused_dpre[s.base.data_ptr()] = dp
+                    o += s.C
+                    continue
                 ds = self.grad(s)
                 if in_slope is None:
                     e.conv(pkT, [dsrc_in], ds, res=ds)  # in place: ds += conv
