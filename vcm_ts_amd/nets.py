@@ -210,17 +210,28 @@ class Net:
         f = self.res_block(f"{n}.res2", enc_cat3, slope=0.1, end_with_relu=True)
         return self.conv(f"{n}.conv4", self.conv(f"{n}.conv3", f, stride=2), stride=2)
 
+    def _beside_context(self, name, ctx: View) -> View:
+        """The 128-channel buffer [64 new channels | ctx] the contextual decoder's ResBlocks run on (torch.cat((f, context),
+        video_model.py:103,107).  Inference: motion_compensation wrote the context into channels 64..127 of the ENCODER's
+        concat buffer, whose first half (the contextual encoder's features) is dead once y exists -- and in a decode-only
+        call was never written -- so the decoder's features go there and no copy of the context is made (round 4: two
+        copy launches per picture less, same bits).  A recorded training forward keeps every buffer: it copies."""
+        if (self.e.tape is None and ctx.cs == 128 and ctx.coff == 64 and ctx.base.dim() == 4
+                and tuple(ctx.base.shape) == (ctx.N, ctx.H, ctx.W, 128)):
+            return View(ctx.base, 128)
+        cat = self.buf(name, like=ctx, C=128)
+        self.e.copy(ctx, cat.slice(64, 64))
+        return cat
+
     def contextual_decoder(self, y_hat: View, c2: View, c3: View) -> View:
         """video_model.py:93-112."""
         n = "contextual_decoder"
         u1 = self.conv(f"{n}.up1.0", y_hat, ps=True)
-        cat3 = self.buf("dec_cat3", like=c3, C=128)
+        cat3 = self._beside_context("dec_cat3", c3)
         self.conv(f"{n}.up2.0", u1, ps=True, out=cat3.slice(0, 64))
-        self.e.copy(c3, cat3.slice(64, 64))
         f = self.res_block(f"{n}.res1", cat3, slope=0.1, end_with_relu=True)
-        cat2 = self.buf("dec_cat2", like=c2, C=128)
+        cat2 = self._beside_context("dec_cat2", c2)
         self.conv(f"{n}.up3.0", f, ps=True, out=cat2.slice(0, 64))
-        self.e.copy(c2, cat2.slice(64, 64))
         f = self.res_block(f"{n}.res2", cat2, slope=0.1, end_with_relu=True)
         return self.conv(f"{n}.up4.0", f, ps=True)
 
