@@ -89,7 +89,7 @@ typedef struct {
     float *out;           /* (N, Hout*ps, Wout*ps, out_cs) where ps = pixel_shuffle ? 2 : 1 */
     int32_t out_cs;
     int32_t out_act;      /* 0: none, 1: LeakyReLU(out_slope) after bias, 2: clamp to [0, 1], 3 (dcvc_conv2d only;
-                             round 4): res2 is not added but used as a mask source, out *= (res2 > 0 ? 1 : out_slope) --
+                             round 4): res2 is not added but used as a mask source, out = out * (res2 > 0 ? 1 : out_slope) [+ res] --
                              the backward of a producer's LeakyReLU applied by the data-gradient convolution of its only
                              consumer, so that the producer needs no epilogue-backward pass of its own (grad.py) */
     float out_slope;

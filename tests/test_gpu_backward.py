@@ -189,6 +189,49 @@ def test_intra_frame_gradients_match_reference_fixture(precision):
     assert float(out2["mse"].detach().sum()) != float(out["mse"].detach().sum())
 
 
+@pytest.mark.parametrize("precision", ["fp32", "fp16x3"])
+def test_epilogue_backward_fusion_changes_no_bit(precision):
+    """Tape._plan_fusion (round 4): where a LeakyReLU-only layer has a single consumer, and where a layer applies its
+    activation on load, the activation's derivative rides on the data-gradient convolution's epilogue
+    (dcvc_conv_args.out_act 3) instead of a launch of its own.  Every parameter gradient, both q-scale gradients and the
+    gradient that reaches the DPB of two chained pictures must equal the unfused pass bit for bit."""
+    from vcm_ts_amd.dmc import DMC
+    from vcm_ts_amd.grad import Tape
+    from vcm_ts_amd.synthetic import frames
+
+    dev = torch.device("cuda:0")
+    fr = frames(12, 6, 64, 64)
+    x0, x1, x2 = (torch.from_numpy(fr[2 * k:2 * k + 2]).to(dev) for k in range(3))
+    g = torch.Generator().manual_seed(3)
+    noise = [{k: (torch.rand(s_, generator=g) - 0.5).to(dev) for k, s_ in (("y", (2, 96, 4, 4)), ("mv_y", (2, 64, 4, 4)),
+                                                                         ("z", (2, 64, 1, 1)), ("mv_z", (2, 64, 1, 1)))} for _ in range(2)]
+    got = {}
+    for fused in (False, True):
+        Tape.epilogue_fusion = fused
+        try:
+            m = DMC(precision=precision).to(dev).train()
+            for p in m.parameters():
+                p.requires_grad_(True)
+            qm = torch.tensor([1.0, 0.8], device=dev).view(2, 1, 1, 1).requires_grad_()
+            qy = torch.tensor([1.2, 0.9], device=dev).view(2, 1, 1, 1).requires_grad_()
+            dpb = {"ref_frame": x0, "ref_feature": None, "ref_y": None, "ref_mv_y": None}
+            total = 0.0
+            for t, x in enumerate((x1, x2)):  # cascade: the second picture back-propagates into the first through the DPB
+                m._noise_override = noise[t]
+                out = m.forward_one_frame(x, dpb, qm, qy)
+                total = total + torch.mean(out["bpp"] + 50.0 * out["mse"] + 10.0 * out["me_mse"])
+                dpb = out["dpb"]
+            total.backward()
+            m._noise_override = None
+            got[fused] = ({k: v.grad.clone() for k, v in m.named_parameters() if v.grad is not None}, qm.grad.clone(), qy.grad.clone())
+        finally:
+            Tape.epilogue_fusion = True
+    assert got[True][0].keys() == got[False][0].keys() and len(got[True][0]) > 390
+    for k, v in got[False][0].items():
+        assert torch.equal(got[True][0][k], v), k
+    assert torch.equal(got[True][1], got[False][1]) and torch.equal(got[True][2], got[False][2])
+
+
 def test_reverse_pass_enqueues_no_aten_arithmetic_beside_the_weight_gradient_stream():
     """the library is built without packed-FP32 instructions because one of its kernels once computed
     differently while 16-bit-MFMA kernels shared the SIMDs; ATen's arithmetic kernels are not built that

@@ -363,21 +363,22 @@ __global__ __launch_bounds__(256, 2) void conv_mfma(const ConvK a) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = fminf(fmaxf(v[e], 0.f), 1.f);
                 }
-                if (a.res) {
-                    if (a.res_gate) {  // explicit fma: the same rounding in every kernel that applies the SE gate
+                if (a.out_act == 3) {  // res2 is a MASK SOURCE (dcvc_hip.h): v = v * LeakyReLU'(res2) [+ res], each rounded
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaf(rv[m][it][e], gate[e], v[e]);
-                    } else {
-                        v = v + rv[m][it];
+                    for (int e = 0; e < 4; ++e) {
+                        v[e] = __fmul_rn(v[e], rv2[m][it][e] > 0.f ? 1.f : a.out_slope);
+                        if (a.res) v[e] = __fadd_rn(rv[m][it][e], v[e]);
                     }
-                }
-                if (a.res2) {
-                    if (a.out_act == 3) {  // res2 is a MASK SOURCE: v *= LeakyReLU'(res2) (dcvc_hip.h, out_act 3)
+                } else {
+                    if (a.res) {
+                        if (a.res_gate) {  // explicit fma: the same rounding in every kernel that applies the SE gate
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] *= rv2[m][it][e] > 0.f ? 1.f : a.out_slope;
-                    } else {
-                        v = rv2[m][it] + v;
+                            for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaf(rv[m][it][e], gate[e], v[e]);
+                        } else {
+                            v = v + rv[m][it];
+                        }
                     }
+                    if (a.res2) v = rv2[m][it] + v;
                 }
                 if (a.chan_partial && ok[m][it]) csum += v;
                 if (a.status && ok[m][it])
@@ -443,8 +444,13 @@ __global__ __launch_bounds__(256, 2) void conv_mfma(const ConvK a) {
                 else if (a.out_act == 2) v = fminf(fmaxf(v, 0.f), 1.f);
                 const size_t pix = a.ps ? ((size_t)(img * Ho + 2 * oy + dy) * Wo + 2 * ox + dx)
                                         : ((size_t)(img * Ho + oy) * Wo + ox);
-                if (a.res) v = a.res_gate ? __builtin_fmaf(rv[r], gate, v) : v + rv[r];
-                if (a.res2) v = a.out_act == 3 ? v * (rv2[r] > 0.f ? 1.f : a.out_slope) : rv2[r] + v;
+                if (a.out_act == 3) {
+                    v = __fmul_rn(v, rv2[r] > 0.f ? 1.f : a.out_slope);
+                    if (a.res) v = __fadd_rn(rv[r], v);
+                } else {
+                    if (a.res) v = a.res_gate ? __builtin_fmaf(rv[r], gate, v) : v + rv[r];
+                    if (a.res2) v = rv2[r] + v;
+                }
                 if (a.status) vmax = fmaxf(vmax, fabsf(v));
                 a.out[pix * a.out_cs + cf] = v;
             }

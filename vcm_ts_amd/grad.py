@@ -42,6 +42,7 @@ class Tape:
         self.pool = []        # zero-filled chunks the gradient buffers are carved from (one memset each)
         self.pool_left = 0
         self.parena = None    # (flat zero-filled tensor, {id(parameter): offset}) when parameter gradients share one buffer
+        self.small, self.small_left = None, 0  # zeroed chunk for the small parameter gradients (pgrad)
         self.fused_dpre = {}  # forward base data_ptr of a convolution output -> its pre-activation gradient, already
                               # computed by the data-gradient launch of its only consumer (round 4, _plan_fusion)
         self.fuse = {}        # forward base data_ptr -> the producing conv op, for outputs eligible for that fusion
@@ -89,6 +90,17 @@ class Tape:
                 # graph zeroes with a single fill and hands out with a single copy
                 off = self.parena[1][id(p)]
                 g = self.parena[0][off : off + p.numel()].view(p.shape)
+            elif zero and p.numel() <= 4096:
+                # small accumulated gradients (factorised-prior and SE parameters, q_basic: ~100 per step) share one
+                # dedicated zeroed chunk instead of costing a fill launch each; the chunk lives as long as those
+                # gradients do (it is NOT the pool of activation gradients: that one must die with the tape)
+                if self.small_left < p.numel():
+                    self.small = torch.zeros(1 << 18, dtype=torch.float32, device=self.e.device)
+                    self.small_left = self.small.numel()
+                off = self.small.numel() - self.small_left
+                n4 = (p.numel() + 3) // 4 * 4
+                self.small_left -= n4
+                g = self.small[off : off + p.numel()].view(p.shape)
             else:
                 g = (torch.zeros_like if zero else torch.empty_like)(p, memory_format=torch.contiguous_format)
             self.pgrads[id(p)] = g
@@ -299,6 +311,10 @@ class Tape:
                 ds = self.grad(s)
                 if in_slope is None:
                     e.conv(pkT, [dsrc_in], ds, res=ds)  # in place: ds += conv
+                elif self.epilogue_fusion:
+                    # activation on load in the forward: ds += conv * act'(s), in the launch's own epilogue (out_act 3 with
+                    # a residual: product and sum rounded separately, as dcvc_mask_accumulate rounds them)
+                    e.conv(pkT, [dsrc_in], ds, res=ds, out_slope=("mask", float(in_slope)), res2=s)
                 else:
                     tmp = View(torch.empty((s.N, s.H, s.W, _r4(s.C)), dtype=torch.float32, device=e.device), s.C)
                     e.conv(pkT, [dsrc_in], tmp)
