@@ -207,7 +207,7 @@ def test_epilogue_backward_fusion_changes_no_bit(precision):
                                                                          ("z", (2, 64, 1, 1)), ("mv_z", (2, 64, 1, 1)))} for _ in range(2)]
     got = {}
     for fused in (False, True):
-        Tape.epilogue_fusion = fused
+        Tape.epilogue_fusion = 3 if fused else 0
         try:
             m = DMC(precision=precision).to(dev).train()
             for p in m.parameters():
@@ -225,7 +225,7 @@ def test_epilogue_backward_fusion_changes_no_bit(precision):
             m._noise_override = None
             got[fused] = ({k: v.grad.clone() for k, v in m.named_parameters() if v.grad is not None}, qm.grad.clone(), qy.grad.clone())
         finally:
-            Tape.epilogue_fusion = True
+            Tape.epilogue_fusion = 3
     assert got[True][0].keys() == got[False][0].keys() and len(got[True][0]) > 390
     for k, v in got[False][0].items():
         assert torch.equal(got[True][0][k], v), k

@@ -633,11 +633,11 @@ __global__ void mask_accumulate_kernel(const float *__restrict__ src, int src_cs
     if (gid >= npix * C) return;
     const int c = (int)(gid % C);
     const int64_t p = gid / C;
-    float v = src[p * src_cs + c];
-    // (explicitly rounded product and sum: the same two roundings as the fused form of this operation in the
-    // data-gradient convolution's epilogue, dcvc_conv_args.out_act 3 with a residual -- no contraction into an fma)
-    if (x) v = __fmul_rn(v, x[p * x_cs + c] > 0.f ? 1.f : slope);
-    dst[p * dst_cs + c] = __fadd_rn(dst[p * dst_cs + c], v);
+    const float v = src[p * src_cs + c];
+    // (an explicit fma: the same single rounding as the fused form of this operation in the data-gradient convolution's
+    // epilogue, dcvc_conv_args.out_act 3 with a residual -- whatever the compiler's contraction choices in either kernel)
+    const float m = x ? (x[p * x_cs + c] > 0.f ? 1.f : slope) : 1.f;
+    dst[p * dst_cs + c] = __builtin_fmaf(v, m, dst[p * dst_cs + c]);
 }
 
 __global__ void add_planes_kernel(const float *__restrict__ a, int a_cs, const float *__restrict__ b, int b_cs,

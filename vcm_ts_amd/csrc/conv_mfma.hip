@@ -363,11 +363,11 @@ __global__ __launch_bounds__(256, 2) void conv_mfma(const ConvK a) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = fminf(fmaxf(v[e], 0.f), 1.f);
                 }
-                if (a.out_act == 3) {  // res2 is a MASK SOURCE (dcvc_hip.h): v = v * LeakyReLU'(res2) [+ res], each rounded
+                if (a.out_act == 3) {  // res2 is a MASK SOURCE (dcvc_hip.h): v = v * LeakyReLU'(res2) [+ res]
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        v[e] = __fmul_rn(v[e], rv2[m][it][e] > 0.f ? 1.f : a.out_slope);
-                        if (a.res) v[e] = __fadd_rn(rv[m][it][e], v[e]);
+                    for (int e = 0; e < 4; ++e) {  // (with a residual: ONE rounding, as dcvc_mask_accumulate's fma)
+                        const float mk = rv2[m][it][e] > 0.f ? 1.f : a.out_slope;
+                        v[e] = a.res ? __builtin_fmaf(v[e], mk, rv[m][it][e]) : v[e] * mk;
                     }
                 } else {
                     if (a.res) {
@@ -445,8 +445,8 @@ __global__ __launch_bounds__(256, 2) void conv_mfma(const ConvK a) {
                 const size_t pix = a.ps ? ((size_t)(img * Ho + 2 * oy + dy) * Wo + 2 * ox + dx)
                                         : ((size_t)(img * Ho + oy) * Wo + ox);
                 if (a.out_act == 3) {
-                    v = __fmul_rn(v, rv2[r] > 0.f ? 1.f : a.out_slope);
-                    if (a.res) v = __fadd_rn(rv[r], v);
+                    const float mk = rv2[r] > 0.f ? 1.f : a.out_slope;
+                    v = a.res ? __builtin_fmaf(v, mk, rv[r]) : v * mk;
                 } else {
                     if (a.res) v = a.res_gate ? __builtin_fmaf(rv[r], gate, v) : v + rv[r];
                     if (a.res2) v = rv2[r] + v;

@@ -153,7 +153,8 @@ class Tape:
             e.guard_outputs = guard
 
     # -- convolution ----------------------------------------------------------------------
-    epilogue_fusion = True  # (developer A/B: False keeps one epilogue-backward launch per activated convolution)
+    epilogue_fusion = 3  # bit 0: single-consumer LeakyReLU layers, bit 1: activation-on-load layers (developer A/B: 0 = one
+                         # epilogue-backward / mask-accumulate launch per layer, as rounds 1-3)
 
     def _plan_fusion(self):
         """Which convolution outputs get their epilogue backward from their consumer (round 4).  A layer whose epilogue is
@@ -164,7 +165,7 @@ class Tape:
         values are the same bit for bit (0 + v, then v * m).  Eligibility is decided by counting every appearance of a
         forward buffer among the recorded operations' arguments: producer + one consumer = 2."""
         self.fuse, self.fused_dpre = {}, {}
-        if not self.epilogue_fusion:
+        if not (self.epilogue_fusion & 1):
             return
         uses, producer = {}, {}
 
@@ -311,9 +312,9 @@ class Tape:
                 ds = self.grad(s)
                 if in_slope is None:
                     e.conv(pkT, [dsrc_in], ds, res=ds)  # in place: ds += conv
-                elif self.epilogue_fusion:
+                elif self.epilogue_fusion & 2:
                     # activation on load in the forward: ds += conv * act'(s), in the launch's own epilogue (out_act 3 with
-                    # a residual: product and sum rounded separately, as dcvc_mask_accumulate rounds them)
+                    # a residual: one fma, as dcvc_mask_accumulate computes it)
                     e.conv(pkT, [dsrc_in], ds, res=ds, out_slope=("mask", float(in_slope)), res2=s)
                 else:
                     tmp = View(torch.empty((s.N, s.H, s.W, _r4(s.C)), dtype=torch.float32, device=e.device), s.C)
