@@ -606,6 +606,29 @@ def test_k32_wave_count_changes_no_bit(eng_split):
     assert torch.isfinite(got[8][1][: N * parts * pk.Cout_pad]).all()
 
 
+@pytest.mark.parametrize("ks,cin,cout,H,W", [(3, 64, 64, 68, 120), (3, 96, 32, 68, 120), (1, 64, 128, 68, 120), (3, 128, 48, 61, 97)])
+def test_small_launches_on_4_row_tiles_change_no_bit(eng, eng_split, ks, cin, cout, H, W):
+    """dcvc_conv2d runs a stride-1 layer with few workgroups on 4-row tiles instead of 8-row tiles (round 4: twice the
+    workgroups for the 1/16-resolution stages and for small training batches).  The tile shape must not enter an output's
+    sum: the same picture alone (few workgroups: 4-row tiles) and as the first of a batch of twelve (enough workgroups:
+    8-row tiles) gives the same bits, with residual and activation, in both arithmetic modes."""
+    g = torch.Generator().manual_seed(ks * 100 + cin)
+    x = torch.randn(12, cin, H, W, generator=g)
+    r = torch.randn(12, cout, H, W, generator=g)
+    w = torch.randn(cout, cin, ks, ks, generator=g) / math.sqrt(cin * ks * ks)
+    b = torch.randn(cout, generator=g)
+    for e in (eng, eng_split):
+        pk = e.pack(("rows4", ks, cin, cout), torch.nn.Parameter(w.cuda()), torch.nn.Parameter(b.cuda()), (cin,), False)
+        outs = []
+        for n in (1, 12):
+            xin, res = to_view(e, f"r4/in{n}", x[:n]), to_view(e, f"r4/res{n}", r[:n])
+            out = e.buf(f"r4/out{n}", n, H, W, cout)
+            out.base.fill_(float("nan"))
+            e.conv(pk, [xin], out, res=res, out_slope=0.1, in_slope=0.01)
+            outs.append(e.to_nchw(out)[0].clone())
+        assert torch.isfinite(outs[0]).all() and torch.equal(outs[0], outs[1]), (e.precision, ks, cin, cout)
+
+
 def test_build_indexes_bit_exact_against_reference_planes(eng):
     """GaussianEncoder.build_indexes (entropy_models.py:264-268) on the device, integer-equal to what
     the REFERENCE produced: its sweep over bin edges / zeros / negatives (tables.npz) and the index

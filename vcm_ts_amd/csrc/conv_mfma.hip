@@ -650,6 +650,19 @@ extern "C" int dcvc_conv2d(const dcvc_conv_args *a, void *stream) {
     hipStream_t st = (hipStream_t)stream;
     const bool wide = (a->Cout_pad % 64) == 0;
     const int key = a->ks * 10 + a->stride;
+    // Small launches (round 4): a stride-1 layer whose 8-row tiles would not even put 1.5 workgroups on every CU runs on
+    // 4-row tiles instead -- twice the workgroups, each half the work.  The 1/16- and 1/64-resolution stages of a 1080p
+    // picture (36 tiles of 8 x 32 pixels) and most layers of a 256 x 256 training batch are such launches.  A tile's
+    // shape changes nothing in an output's sum (chunks and taps in the same order): bit-identical, whatever the batch
+    // size decides here (tests/test_gpu_kernels.py).  Not for the fused channel sums (their partial rows are per tile)
+    // nor for band launches (the band unit is the 8-row tile).
+    if (a->stride == 1 && (a->ks == 1 || a->ks == 3) && !a->chan_partial && a->tile_rows <= 0) {
+        const long wgs8 = (long)((k.Wout + 31) / 32) * ((k.Hout + 7) / 8) * (a->Cout_pad / (wide ? 64 : 32)) * a->N;
+        if (wgs8 < 384) {
+            if (a->ks == 3) return wide ? launch<3, 1, 1, 2>(k, a->N, st, a->precision) : launch<3, 1, 1, 1>(k, a->N, st, a->precision);
+            return wide ? launch<1, 1, 1, 2>(k, a->N, st, a->precision) : launch<1, 1, 1, 1>(k, a->N, st, a->precision);
+        }
+    }
     switch (key) {
         case 11: return wide ? launch<1, 1, 2, 2>(k, a->N, st, a->precision) : launch<1, 1, 2, 1>(k, a->N, st, a->precision);
         case 12: return wide ? launch<1, 2, 1, 2>(k, a->N, st, a->precision) : launch<1, 2, 1, 1>(k, a->N, st, a->precision);
