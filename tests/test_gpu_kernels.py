@@ -606,7 +606,8 @@ def test_k32_wave_count_changes_no_bit(eng_split):
     assert torch.isfinite(got[8][1][: N * parts * pk.Cout_pad]).all()
 
 
-@pytest.mark.parametrize("ks,cin,cout,H,W", [(3, 64, 64, 68, 120), (3, 96, 32, 68, 120), (1, 64, 128, 68, 120), (3, 128, 48, 61, 97)])
+@pytest.mark.parametrize("ks,cin,cout,H,W", [(3, 64, 64, 68, 120), (3, 96, 32, 68, 120), (1, 64, 128, 68, 120), (3, 128, 48, 61, 97), (7, 32, 64, 68, 120),
+                                             (7, 16, 32, 34, 60)])
 def test_small_launches_on_4_row_tiles_change_no_bit(eng, eng_split, ks, cin, cout, H, W):
     """dcvc_conv2d runs a stride-1 layer with few workgroups on 4-row tiles instead of 8-row tiles (round 4: twice the
     workgroups for the 1/16-resolution stages and for small training batches).  The tile shape must not enter an output's

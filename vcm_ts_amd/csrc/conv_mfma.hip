@@ -656,11 +656,14 @@ extern "C" int dcvc_conv2d(const dcvc_conv_args *a, void *stream) {
     // shape changes nothing in an output's sum (chunks and taps in the same order): bit-identical, whatever the batch
     // size decides here (tests/test_gpu_kernels.py).  Not for the fused channel sums (their partial rows are per tile)
     // nor for band launches (the band unit is the 8-row tile).
-    if (a->stride == 1 && (a->ks == 1 || a->ks == 3) && !a->chan_partial && a->tile_rows <= 0) {
+    if (a->stride == 1 && !a->pair_taps && !a->chan_partial && a->tile_rows <= 0) {
         const long wgs8 = (long)((k.Wout + 31) / 32) * ((k.Hout + 7) / 8) * (a->Cout_pad / (wide ? 64 : 32)) * a->N;
-        if (wgs8 < 384) {
+        // (developer A/B of the threshold: DCVC_ROWS4_WGS, read once; any value gives the same bits)
+        static const long rows4_below = getenv("DCVC_ROWS4_WGS") ? atol(getenv("DCVC_ROWS4_WGS")) : 384;
+        if (wgs8 < rows4_below) {
             if (a->ks == 3) return wide ? launch<3, 1, 1, 2>(k, a->N, st, a->precision) : launch<3, 1, 1, 1>(k, a->N, st, a->precision);
-            return wide ? launch<1, 1, 1, 2>(k, a->N, st, a->precision) : launch<1, 1, 1, 1>(k, a->N, st, a->precision);
+            if (a->ks == 7) return wide ? launch<7, 1, 1, 2>(k, a->N, st, a->precision) : launch<7, 1, 1, 1>(k, a->N, st, a->precision);
+            if (a->ks == 1) return wide ? launch<1, 1, 1, 2>(k, a->N, st, a->precision) : launch<1, 1, 1, 1>(k, a->N, st, a->precision);
         }
     }
     switch (key) {
