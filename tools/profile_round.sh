@@ -26,7 +26,7 @@ python3 tools/rocprof_pmc.py $OUT/fetch_results.db FETCH_SIZE > $OUT/${R}_fp16x3
 python3 tools/rocprof_pmc.py $OUT/write_results.db WRITE_SIZE > $OUT/${R}_fp16x3_pmc_write_size.txt
 python3 tools/rocprof_traffic.py $OUT/fetch_results.db $OUT/write_results.db 'conv_k32<3, 4, 8>' fp16x3 1080 1920 > $OUT/traffic_bench.json
 cp profiles/pmc_traffic_fp16x3.json $OUT/pmc_traffic_fp16x3.json
-python3 tools/rocprof_traffic.py $OUT/fetch32_results.db $OUT/write32_results.db 'conv_mfma<3, 1, 2, 2, false' fp32 1080 1920 > $OUT/traffic_bench_fp32.json
+python3 tools/rocprof_traffic.py $OUT/fetch32_results.db $OUT/write32_results.db 'conv_mfma<3, 1, _, 2, false' fp32 1080 1920 > $OUT/traffic_bench_fp32.json
 cp profiles/pmc_traffic_fp32.json $OUT/pmc_traffic_fp32.json
 python3 tools/rocprof_summary.py $OUT/probestats_results.db > $OUT/${R}_conv_probe_64_kernel_stats.txt
 python3 tools/rocprof_pmc.py $OUT/probefetch_results.db FETCH_SIZE > $OUT/${R}_conv_probe_64_pmc_fetch_size.txt
