@@ -128,3 +128,11 @@ def test_engine_routing_ignores_stray_environment(monkeypatch):
         assert f'sw("{name}"' in src and f'os.environ.get("{name}"' not in src, name
     k32 = open(os.path.join(CSRC, "conv_k32.hip")).read()
     assert "getenv" not in k32
+    # the C library: launch-geometry A/B switches (never a result bit) go through dev_env_long, which reads them only
+    # when DCVC_DEV=1 -- no other getenv in the product sources
+    import glob
+    import re
+    for path in sorted(glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.cpp"))):
+        text = open(path).read()
+        body = re.sub(r"inline long dev_env_long\(.*?\n}\n", "", text, flags=re.S)
+        assert "getenv" not in body, os.path.basename(path)

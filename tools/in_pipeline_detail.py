@@ -15,6 +15,7 @@ prec = sys.argv[1] if len(sys.argv) > 1 else "fp16x3"
 flt = sys.argv[2] if len(sys.argv) > 2 else "(64,)->64 1088x1920"
 i_net, p_net = IntraNoAR(precision=prec).to(dev).eval(), DMC(precision=prec).to(dev).eval()
 i_net.update(); p_net.update()
+p_net.fork_features = False  # every launch on one stream: a launch's events then time that launch alone
 seq = [pad_frame(f) for f in synth_sequence(dev, 4, 1080, 1920, 0)]
 dpb = {"ref_frame": i_net.compress(seq[0], 1.0)["x_hat"], "ref_feature": None, "ref_y": None, "ref_mv_y": None}
 dpb = p_net.compress(seq[1], dpb, 1.0, 1.0)["dpb"]

@@ -84,6 +84,16 @@ constexpr float ACT_LIMIT = 65504.f / 8.f;  // F16_MAX / ACT_SCALE
 
 __device__ __forceinline__ float act(float v, float slope) { return v > 0.f ? v : v * slope; }
 
+// Developer A/B switches of this file change launch geometry only (never a result bit) and are honoured only in a process
+// that declares itself a developer run with DCVC_DEV=1, like the routing switches of vcm_ts_amd/engine.py (a
+// stray variable must not reconfigure a product process).
+inline long dev_env_long(const char *name, long dflt) {
+    const char *dev = getenv("DCVC_DEV");
+    if (!dev || strcmp(dev, "1") != 0) return dflt;
+    const char *v = getenv(name);
+    return v ? atol(v) : dflt;
+}
+
 
 __device__ __forceinline__ void split_f16(float v, _Float16 &hi, _Float16 &lo) {
     v = fminf(fmaxf(v * ACT_SCALE, -F16_MAX), F16_MAX);
@@ -470,8 +480,8 @@ int launch(ConvK &k, int N, hipStream_t st, int precision) {
     // fabric reads (each XCD has its own L2).  Measured on 64->64 3x3 at 1088x1920 (tools/xcd_ab.sh): FETCH_SIZE
     // -15 % (traffic 1.32x -> 1.16x of the algorithmic bytes) but the launch takes 3 % LONGER (0.513 -> 0.528 ms):
     // the re-reads were Infinity-Cache hits already, and at the power cap time follows energy,
-    // not fabric requests.  Off by default; DCVC_XCD_PAD=1 turns it on.
-    static const bool xcd_pad = getenv("DCVC_XCD_PAD") ? atoi(getenv("DCVC_XCD_PAD")) != 0 : false;
+    // not fabric requests.  Off; DCVC_DEV=1 DCVC_XCD_PAD=1 turns it on (developer A/B).
+    static const bool xcd_pad = dev_env_long("DCVC_XCD_PAD", 0) != 0;
     unsigned gx = (unsigned)(k.ntx * (k.Cout_pad / BN));
     if (xcd_pad && gx >= 8) gx = (gx + 7) & ~7u;
     k.nty = (k.Hout + BH - 1) / BH;
@@ -658,8 +668,8 @@ extern "C" int dcvc_conv2d(const dcvc_conv_args *a, void *stream) {
     // nor for band launches (the band unit is the 8-row tile).
     if (a->stride == 1 && !a->pair_taps && !a->chan_partial && a->tile_rows <= 0) {
         const long wgs8 = (long)((k.Wout + 31) / 32) * ((k.Hout + 7) / 8) * (a->Cout_pad / (wide ? 64 : 32)) * a->N;
-        // (developer A/B of the threshold: DCVC_ROWS4_WGS, read once; any value gives the same bits)
-        static const long rows4_below = getenv("DCVC_ROWS4_WGS") ? atol(getenv("DCVC_ROWS4_WGS")) : 384;
+        // (developer A/B of the threshold: DCVC_DEV=1 DCVC_ROWS4_WGS=n, read once; any value gives the same bits)
+        static const long rows4_below = dev_env_long("DCVC_ROWS4_WGS", 384);
         if (wgs8 < rows4_below) {
             if (a->ks == 3) return wide ? launch<3, 1, 1, 2>(k, a->N, st, a->precision) : launch<3, 1, 1, 1>(k, a->N, st, a->precision);
             if (a->ks == 7) return wide ? launch<7, 1, 1, 2>(k, a->N, st, a->precision) : launch<7, 1, 1, 1>(k, a->N, st, a->precision);
