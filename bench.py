@@ -570,9 +570,10 @@ def main():
                 "launches_per_p_frame": dom["launches"] // 2, "avg_launch_ms": round(dom["ms"] / max(dom["launches"], 1), 4),
                 "measured": "HIP events around every launch, one GOP stream on the GPU (the kernel by itself)",
                 "all_conv_tflops": round(all_flops / (all_ms * 1e-3) / 1e12, 2), "conv_ms_per_p_frame": round(all_ms / 2, 2),
-                "power_note": "on all-zero operands (full 2.4 GHz clock, minimal power) the kernel takes 84 % of its random-data "
-                              "time (profiles/r03_conv_data_probe_rand_vs_zero.txt): board power costs ~16 %, the rest is the "
-                              "kernel's phase structure and HBM write-back (stamps in profiles/r03_conv_k32_stamps.txt); DESIGN.md 4.1",
+                "power_note": "on all-zero operands (full 2.4 GHz clock, minimal power) the kernel takes 76 % of its random-data "
+                              "time on the probe layer (0.338 vs 0.444 ms, profiles/r04_conv_k32_ablations_late.txt; round 3: 84 %): "
+                              "on real data the board's power limit costs about a quarter, the rest is the kernel's phase "
+                              "structure (stamps in profiles/r03_conv_k32_stamps.txt); DESIGN.md 4.1 item 9",
                 "dominant_profile_key": dom_key,
                 # the HBM-bound kernels of the path (warp, resamplers, dual prior, layout), per shape: HIP
                 # events around every launch of the same two P pictures, algorithmic bytes (each operand once) / time,
