@@ -139,6 +139,12 @@ __global__ __launch_bounds__(64 * NWAVE, NWAVE / 2) void conv_k32(const K32 a) {
     auto ld16 = [](const void *base, unsigned byte_off) __attribute__((always_inline)) {
         return *(const f32x4 *)((const char *)base + byte_off);
     };
+    // Staging slot -> patch pixel: the middle two of every four consecutive slots are swapped (0 2 1 3).  A ds_write_b64 is
+    // served in groups of 16 lanes = two pixels' 64-byte halves; with neighbouring pixels (records 160 B = 40 banks apart,
+    // stores banked modulo 32) those overlap on 8 banks -- the 7 % bank-conflict cycles of profiles/r03_..._sq_counters.txt
+    // -- while pixels two apart (80 banks = 16 modulo 32) do not.  Which lane stages which pixel changes no value.
+    static_assert((PH * PW) % 4 == 0, "slot_pixel permutes inside groups of four pixels");
+    auto slot_pixel = [](int q) __attribute__((always_inline)) { return (q & ~3) | ((q & 1) << 1) | ((q >> 1) & 1); };
     auto load_patch = [&](const Cursor &k) {
         const unsigned cs4 = (unsigned)a.seg_cs[k.s] * 4u;  // bytes per pixel of this segment (< 2^24)
         const char *sp = (const char *)(a.seg_ptr[k.s] + (size_t)img * a.H * a.W * a.seg_cs[k.s] + k.c0);
@@ -152,7 +158,7 @@ __global__ __launch_bounds__(64 * NWAVE, NWAVE / 2) void conv_k32(const K32 a) {
 #pragma unroll
         for (int u = 0; u < NP; ++u) {
             const int i = t + u * NTH;
-            const int p = i >> 3;
+            const int p = slot_pixel(i >> 3);
             const int py = PW == 34 ? (p * 241) >> 13 : p / PW, px = p - py * PW;
             const int gy = y0 - PAD + py, gx = x0 - PAD + px;
             // (bitwise on purpose: && would turn every slot into a branch)
@@ -183,7 +189,7 @@ __global__ __launch_bounds__(64 * NWAVE, NWAVE / 2) void conv_k32(const K32 a) {
                 for (int e = 0; e < 4; ++e) sv[e] = __builtin_amdgcn_fmed3f(sv[e], -F16_MAX, F16_MAX);
                 const f16x4 hi = __builtin_convertvector(sv, f16x4);
                 const f16x4 lo = __builtin_convertvector(sv - __builtin_convertvector(hi, f32x4), f16x4);
-                _Float16 *rec = (_Float16 *)&patch[(i >> 3) * REC];
+                _Float16 *rec = (_Float16 *)&patch[slot_pixel(i >> 3) * REC];
                 *(f16x4 *)&rec[(i & 7) * 4] = hi;
                 *(f16x4 *)&rec[32 + (i & 7) * 4] = lo;
             }
