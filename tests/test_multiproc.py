@@ -1,4 +1,4 @@
-"""N > 1 orchestration on CPU: world_size-2 gloo.  GOPs are independent units, so sharding
+"""N > 1 orchestration on CPU: gloo with 2 and with 8 ranks.  GOPs are independent units, so sharding
 needs no data-path collective; what must hold is that the shards partition the work, that a
 rank's output does not depend on the world size, and that the timing reduction used by
 bench.py (barrier, MAX over ranks) behaves.  The per-GOP work here is the host half of the
@@ -63,9 +63,12 @@ def test_shards_partition_the_gops():
         assert max(len(s) for s in shards) - min(len(s) for s in shards) <= 1
 
 
-@pytest.mark.timeout(120)
-def test_two_rank_gloo_run_matches_single_process():
-    n_gops, world = 5, 2
+@pytest.mark.timeout(240)
+@pytest.mark.parametrize("n_gops,world", [(5, 2), (19, 8)], ids=["2-ranks", "8-ranks"])
+def test_gloo_run_matches_single_process(n_gops, world):
+    """world 8 is the rank count of the node BASELINE's configs[3] and the scaling curve are quoted on: no such node
+    was available to any round, so the orchestration (shards, barrier, MAX-reduced time, gather) is at least run at
+    that size here (gloo, CPU; 19 GOPs: ranks with three and with two GOPs)."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
