@@ -27,3 +27,25 @@ def pytest_sessionstart(session):
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
+
+
+def _cache_synthetic_frames():
+    """vcm_ts_amd.synthetic.frames takes 5 s for eight 1080p pictures and a dozen bench-size tests ask for the same
+    ones: keep the longest sequence generated per (seed, size, noise) and hand out copies of its prefix (frame t does
+    not depend on how many frames follow it: the generator draws them in order)."""
+    import vcm_ts_amd.synthetic as S
+
+    plain, kept = S.frames, {}
+
+    def frames(seed, n_frames, h, w, noise=1.0 / 255.0):
+        key = (int(seed), int(h), int(w), float(noise))
+        have = kept.get(key)
+        if have is None or have.shape[0] < n_frames:
+            have = kept[key] = plain(seed, n_frames, h, w, noise)
+        return have[:n_frames].copy()
+
+    frames.__doc__ = plain.__doc__
+    S.frames = frames
+
+
+_cache_synthetic_frames()

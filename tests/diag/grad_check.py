@@ -136,6 +136,19 @@ def resample_cases(e):
     return worst
 
 
+_ORACLE_STEPS = {}
+
+
+def _detached(v):
+    if torch.is_tensor(v):
+        return v.detach()
+    if isinstance(v, dict):
+        return {k: _detached(x) for k, x in v.items()}
+    if isinstance(v, (list, tuple)):
+        return type(v)(_detached(x) for x in v)
+    return v
+
+
 def frame_case(size=64, N=2, second=True, lam=50.0, verbose=True, precision="fp32"):
     torch.manual_seed(0)
     w0 = seeded_state_dict(dmc_spec())
@@ -157,12 +170,18 @@ def frame_case(size=64, N=2, second=True, lam=50.0, verbose=True, precision="fp3
                  "mv_y": torch.rand(N, 64, size // 16, size // 16, generator=g) - 0.5,
                  "z": torch.rand(N, 64, size // 64, size // 64, generator=g) - 0.5,
                  "mv_z": torch.rand(N, 64, size // 64, size // 64, generator=g) - 0.5}
-        w = {k: v.clone().requires_grad_() for k, v in w0.items()}
-        qm_o, qy_o = q_mv.clone().requires_grad_(), q_y.clone().requires_grad_()
-        with R.training_mode():
-            ro = R.dmc_forward_one_frame(w, x, dpb_o, qm_o, qy_o, noise=noise)
-        loss_o = torch.mean(ro["bpp"] + lam * ro["mse"] + 10.0 * ro["me_mse"])
-        loss_o.backward()
+        # the oracle's forward + autograd backward of this step: once per (size, N, step, lam) and process -- the tests
+        # run this case in both arithmetic modes against the same oracle numbers
+        ck = (size, N, step, lam)
+        if ck not in _ORACLE_STEPS:
+            w = {k: v.clone().requires_grad_() for k, v in w0.items()}
+            qm_o, qy_o = q_mv.clone().requires_grad_(), q_y.clone().requires_grad_()
+            with R.training_mode():
+                ro = R.dmc_forward_one_frame(w, x, dpb_o, qm_o, qy_o, noise=noise)
+            loss_o = torch.mean(ro["bpp"] + lam * ro["mse"] + 10.0 * ro["me_mse"])
+            loss_o.backward()
+            _ORACLE_STEPS[ck] = (w, qm_o, qy_o, _detached(ro), loss_o.detach())
+        w, qm_o, qy_o, ro, loss_o = _ORACLE_STEPS[ck]
         m._noise_override = noise
         m.zero_grad(set_to_none=True)
         qm_g, qy_g = q_mv.clone().to(dev).requires_grad_(), q_y.clone().to(dev).requires_grad_()
