@@ -136,3 +136,17 @@ def test_engine_routing_ignores_stray_environment(monkeypatch):
         text = open(path).read()
         body = re.sub(r"inline long dev_env_long\(.*?\n}\n", "", text, flags=re.S)
         assert "getenv" not in body, os.path.basename(path)
+
+
+def test_developer_switch_patch_applies_to_the_product_kernel(tmp_path):
+    """__graft_entry__.build() also builds tools/probes, whose conv_k32_dev.hip is the product kernel with
+    tools/probes/conv_k32_dev_switches.patch applied: an edit of conv_k32.hip that the patch no longer fits would fail the
+    round's build check (it did once, round 4) -- so it fails here first."""
+    if shutil.which("patch") is None:
+        pytest.skip("patch not installed")
+    out = tmp_path / "conv_k32_dev.hip"
+    r = subprocess.run(["patch", "-s", "-o", str(out), os.path.join(CSRC, "conv_k32.hip"),
+                        os.path.join(ROOT, "tools", "probes", "conv_k32_dev_switches.patch")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    text = out.read_text()
+    assert "K32_ABLATE" in text and "slot_pixel" in text
