@@ -150,3 +150,31 @@ def test_developer_switch_patch_applies_to_the_product_kernel(tmp_path):
     assert r.returncode == 0, r.stdout + r.stderr
     text = out.read_text()
     assert "K32_ABLATE" in text and "slot_pixel" in text
+
+
+@pytest.mark.parametrize("sizes", [0, 8], ids=["zero-sizes", "null-pointers"])
+def test_every_entry_point_refuses_null_and_empty_arguments(sizes):
+    """Every status-returning entry point of include/dcvc_hip*.h, called with NULL pointers (zeroed argument structs) and
+    either zero or plausible sizes, must answer DCVC_E_ARG before anything is launched or dereferenced -- a caller's bug
+    must not become a GPU fault (which on this pool can reset a whole node).  Host-only: a refused call touches no GPU."""
+    import ctypes as C
+
+    from vcm_ts_amd import lib
+
+    L = lib.hip()
+    for name, sig in lib._SIGS.items():
+        if name in ("dcvc_conv_k32_set_waves", "dcvc_pack_plan_destroy"):  # a mode switch; a void destructor (NULL is a no-op)
+            continue
+        args, keep = [], []
+        for t in sig:
+            if t in (lib.i32, lib.i64):
+                args.append(sizes)
+            elif t is lib.f32:
+                args.append(1.0)
+            elif t is lib.vp:
+                args.append(None)
+            else:  # POINTER(argument struct): all fields zero
+                keep.append(t._type_())
+                args.append(C.byref(keep[-1]))
+        assert getattr(L, name)(*args) == -1, name
+    L.dcvc_pack_plan_destroy(None)
