@@ -184,6 +184,22 @@ def test_error_codes(laplace_tables):
         dec.set_stream(b"abc")
 
 
+def test_null_handles_and_buffers_are_refused():
+    """The raw C ABI (include/dcvc_rans.h) with NULL handles / buffers: a status code, never a dereference."""
+    from vcm_ts_amd import lib
+
+    L = lib.rans()
+    assert L.dcvc_rans_encoder_reset(None) == -1
+    assert L.dcvc_rans_encoder_encode_with_indexes(None, None, None, 4, None, 1, 1, None, None) == -1
+    assert L.dcvc_rans_encoder_flush_bound(None) == -1
+    assert L.dcvc_rans_encoder_flush(None, None, 0) == -1
+    assert L.dcvc_rans_decoder_set_stream(None, None, 0) == -1
+    assert L.dcvc_rans_decoder_decode_stream(None, None, 4, None, 1, 1, None, None, None) == -1
+    assert L.dcvc_pmf_to_quantized_cdf(None, 0, 16, None) == -1
+    L.dcvc_rans_encoder_destroy(None)  # (destroying nothing is a no-op)
+    L.dcvc_rans_decoder_destroy(None)
+
+
 def test_corrupt_escape_count_is_rejected(laplace_tables):
     """A stream whose escape announces more than 8 raw nibbles cannot come from any encoder (a 32-bit
     value has 8): the product decoder must return DCVC_RANS_E_STREAM instead of shifting an int32 by
