@@ -2,6 +2,8 @@
 pure-Python restatements, golden byte strings, tables vs reference-generated fixtures."""
 import ctypes as C
 import os
+import shutil
+import subprocess
 
 import numpy as np
 import pytest
@@ -198,6 +200,23 @@ def test_null_handles_and_buffers_are_refused():
     assert L.dcvc_pmf_to_quantized_cdf(None, 0, 16, None) == -1
     L.dcvc_rans_encoder_destroy(None)  # (destroying nothing is a no-op)
     L.dcvc_rans_decoder_destroy(None)
+
+
+@pytest.mark.skipif(shutil.which("g++") is None, reason="g++ not installed")
+def test_decoder_is_memory_safe_on_corrupt_streams_under_asan(tmp_path):
+    """tests/fuzz/rans_fuzz.cpp: the product coder (vcm_ts_amd/csrc/rans.cpp) built with AddressSanitizer + UBSan; random
+    tables and planes (in-table and escape-coded) round-trip, and truncated / bit-flipped / garbage-extended / escape-inflated
+    payloads are answered with a status code or other symbols -- never with an out-of-bounds access (any sanitizer report
+    aborts the run).  A payload comes from a file: the reference's decoder only asserts (rans_interface.cpp:184-244)."""
+    exe = tmp_path / "rans_fuzz"
+    build = subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+                            "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "vcm_ts_amd", "csrc", "rans.cpp"),
+                            os.path.join(ROOT, "tests", "fuzz", "rans_fuzz.cpp"), "-o", str(exe)], capture_output=True, text=True)
+    assert build.returncode == 0, build.stderr[-2000:]
+    for seed in (1, 2, 3):
+        run = subprocess.run([str(exe), "1500", str(seed)], capture_output=True, text=True, timeout=300)
+        assert run.returncode == 0, (seed, run.stdout[-500:], run.stderr[-3000:])
+        assert "rans_fuzz: 1500 rounds" in run.stdout and "refused with a status" in run.stdout
 
 
 def test_corrupt_escape_count_is_rejected(laplace_tables):
