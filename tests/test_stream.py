@@ -121,3 +121,20 @@ def test_png_writer_pool_propagates_failures_and_bounds_its_queue(tmp_path):
     w0 = PNGWriters(0)
     w0.submit(a, str(tmp_path / "inline.png"))
     assert w0.pool is None and (tmp_path / "inline.png").exists()
+
+
+def test_truncated_bin_files_are_refused_by_name(tmp_path):
+    """A .bin file shorter than its own header announces (an interrupted copy) is refused when it is read -- the
+    reference's f.read(n) returns what is left and the entropy decoder runs off the end."""
+    from vcm_ts_amd import stream as S
+
+    pi, pp = str(tmp_path / "i.bin"), str(tmp_path / "p.bin")
+    S.encode_i(1080, 1920, 37, bytes(range(200)), pi)
+    S.encode_p(bytes(range(100)), 12, 34, pp)
+    assert S.decode_i(pi) == (1080, 1920, 37, bytes(range(200))) and S.decode_p(pp) == (12, 34, bytes(range(100)))
+    for path, fn, keep in ((pi, S.decode_i, 150), (pp, S.decode_p, 50), (pi, S.decode_i, 5), (pp, S.decode_p, 3), (pi, S.decode_i, 0)):
+        data = open(path, "rb").read()
+        cut = str(tmp_path / "cut.bin")
+        open(cut, "wb").write(data[:keep])
+        with pytest.raises(ValueError, match="truncated"):
+            fn(cut)

@@ -58,10 +58,26 @@ def encode_i(height, width, q_index, bit_stream, output):
         f.write(bit_stream)
 
 
+def _payload(f, n, inputpath):
+    """The n payload bytes a header announces.  The reference returns whatever is left (f.read(n)) and lets the entropy
+    decoder run off the end; a file shorter than its own header says is refused here, by name."""
+    data = f.read(n)
+    if len(data) != n:
+        raise ValueError(f'"{inputpath}" is truncated: its header announces {n} payload bytes, {len(data)} are there')
+    return data
+
+
+def _header(f, head, inputpath):
+    raw = f.read(head.size)
+    if len(raw) != head.size:
+        raise ValueError(f'"{inputpath}" is truncated: {len(raw)} of {head.size} header bytes')
+    return head.unpack(raw)
+
+
 def decode_i(inputpath):
     with open(inputpath, "rb") as f:
-        height, width, q_index, n = _I_HEAD.unpack(f.read(_I_HEAD.size))
-        return height, width, q_index, f.read(n)
+        height, width, q_index, n = _header(f, _I_HEAD, inputpath)
+        return height, width, q_index, _payload(f, n, inputpath)
 
 
 def encode_p(string, mv_y_q_index, y_q_index, output):
@@ -72,5 +88,5 @@ def encode_p(string, mv_y_q_index, y_q_index, output):
 
 def decode_p(inputpath):
     with open(inputpath, "rb") as f:
-        mv_y_q_index, y_q_index, n = _P_HEAD.unpack(f.read(_P_HEAD.size))
-        return mv_y_q_index, y_q_index, f.read(n)
+        mv_y_q_index, y_q_index, n = _header(f, _P_HEAD, inputpath)
+        return mv_y_q_index, y_q_index, _payload(f, n, inputpath)
