@@ -135,7 +135,7 @@ __global__ __launch_bounds__(64 * NWAVE, NWAVE / 2) void conv_k32(const K32 a) {
     // are recomputed where they are used, a dozen VALU operations per 16-byte load.
     // Address arithmetic is kept off the 64-bit vector ALU: every global access is a wave-uniform base pointer (scalar
     // registers) plus a 32-bit per-lane byte offset (tensors stay below 4 GiB).
-    static_assert(PH * PW * 241 < (1 << 23) && PW == 34 || KS != 3, "the multiply-shift below divides by PW = 34");
+    static_assert((PH * PW * 241 < (1 << 23) && PW == 34) || KS != 3, "the multiply-shift below divides by PW = 34");
     auto ld16 = [](const void *base, unsigned byte_off) __attribute__((always_inline)) {
         return *(const f32x4 *)((const char *)base + byte_off);
     };

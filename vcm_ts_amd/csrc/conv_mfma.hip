@@ -95,12 +95,6 @@ inline long dev_env_long(const char *name, long dflt) {
 }
 
 
-__device__ __forceinline__ void split_f16(float v, _Float16 &hi, _Float16 &lo) {
-    v = fminf(fmaxf(v * ACT_SCALE, -F16_MAX), F16_MAX);
-    hi = (_Float16)v;
-    lo = (_Float16)(v - (float)hi);
-}
-
 // PAIR (7x7, one segment of <= 8 input channels, split mode: SpyNet's first layer): a 16-deep K step would be half
 // zero padding.  Instead the LDS record of patch pixel (y, x) carries the 8 channels of (y, x) in its lower half and
 // the 8 channels of (y, x + 1) in its upper half, and the filter is packed in tap PAIRS (kx = 2j, 2j + 1; the pair of
